@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs only in the development container (the reference lives at /root/reference
+and never travels to the GPU box).  It imports the reference's own hot-path
+modules on CPU -- with inert placeholder modules for the three third-party
+packages that are not installed (bidict, mfst, pynini) --
+feeds them seeded synthetic lattices from ``nfst_amd.synth`` and stores inputs
+and the reference's outputs as small ``.npz`` files (plain arrays, no pickles).
+
+    python tests/golden/make_golden.py
+
+What is pinned (reference file:line):
+  beta_*.npz     FSAGRUScorer.compute_beta_per_sample / compute_beta_parallel
+                 (scorers.py:692-751, 753-856) with Wh = 0, i.e. arc weight
+                 exp(theta[label]);  includes the parallel-arc quirk fixture.
+  gather.npz     set_masks/set_k (877-918), update_fsa_state (683-690),
+                 mask_out_invalid (1037-1054 on top of 314-338) on a collated,
+                 pad-padded batch (dataset_reader.py:175-186).
+  sampler.npz    Sampler.sample / stateful_sample / stripping_pad
+                 (samplers.py:137-335) with the FSAMaskScorer proposal.  (The
+                 reference's forced-scoring mode, to_evaluate != None, raises at
+                 samplers.py:318 -- torch.stack of an empty list -- so it cannot
+                 be pinned.)
+  iwae.npz       Estimators.iwae (estimatros.py:11-44) + WFSTScorer.wfst_score
+                 (scorers.py:1671-1687).
+  evalseq.npz    StaticRNNScorer.evaluate_seq_with_temp arithmetic
+                 (scorers.py:1530-1614, masks 89-134, smoothing 1502-1528) on
+                 supplied score tensors (the RNN itself is out of scope).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+def _install_placeholders():
+    class _bidict(dict):
+        @property
+        def inverse(self):
+            return {v: k for k, v in self.items()}
+
+    m = types.ModuleType("bidict")
+    m.bidict = _bidict
+    sys.modules["bidict"] = m
+
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def create_from_string(self, *a, **k):
+            return self
+
+    m = types.ModuleType("mfst")
+    m.FST = _Inert
+    m.AbstractSemiringWeight = type("AbstractSemiringWeight", (), {})
+    m.BooleanSemiringWeight = type("BooleanSemiringWeight", (), {})
+    sys.modules["mfst"] = m
+    m = types.ModuleType("pynini")
+    m.Fst = object
+    m.Weight = object
+    m.Arc = object
+    sys.modules["pynini"] = m
+
+
+_install_placeholders()
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+
+from src.util.preprocess_util import Vocab  # noqa: E402
+from src.modules.scorers import (  # noqa: E402
+    FSAGRUScorer,
+    FSAMaskScorer,
+    WFSTScorer,
+    StaticRNNScorer,
+    CompositeScorer,
+)
+from src.modules.samplers import Sampler  # noqa: E402
+from src.modules.estimatros import Estimators  # noqa: E402
+
+from nfst_amd import synth  # noqa: E402
+
+torch.set_num_threads(4)
+PAD, BOS, EOS = synth.PAD, synth.BOS, synth.EOS
+
+Vocab.set_non_reserved_offset(3)
+for w in ("input-mark", "output-mark", "insertion-mark"):
+    Vocab.add_word(w)  # -> ids 3, 4, 5
+assert Vocab.lookup("insertion-mark") == 5
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: " + ", ".join(f"{k}{list(np.shape(v))}" for k, v in arrays.items()))
+
+
+def beta_scorer(V, H=8, seed=0):
+    torch.manual_seed(seed)
+    sc = FSAGRUScorer(hid_dim=H, vocab_size=V, pad=PAD, bos=BOS, eos=EOS, use_beta=True, max_length=64)
+    sc.eval()
+    with torch.no_grad():
+        sc.Wh.zero_()  # arc weight depends on the label only
+        sc.beta_bias.copy_(0.3 * torch.randn(H))
+        sc.W.copy_(torch.randn(1, H))
+        emb = sc.embeddings.weight  # [V, H]
+        theta = (sc.W @ torch.tanh(sc.Wx @ emb.t() + sc.beta_bias[:, None])).reshape(-1)
+    sc._probe_weights = {
+        "emb": sc.embeddings.weight.detach().numpy().astype(np.float32),
+        "Wx": sc.Wx.detach().numpy().astype(np.float32),
+        "Wh": sc.Wh.detach().numpy().astype(np.float32),
+        "W": sc.W.detach().numpy().astype(np.float32),
+        "bias": sc.beta_bias.detach().numpy().astype(np.float32),
+    }
+    return sc, theta.detach().numpy().astype(np.float32)
+
+
+def lattice_arrays(lat, prefix=""):
+    em, tr = lat.dense()
+    return {
+        prefix + "emission": em,
+        prefix + "transition": tr,
+        prefix + "src": lat.src,
+        prefix + "label": lat.label,
+        prefix + "dst": lat.dst,
+    }
+
+
+def make_beta():
+    cases = {
+        "beta_layered12": synth.layered_lattice(11, n_states=12, avg_degree=3.0, vocab=47, width=3, span=2),
+        "beta_layered40": synth.layered_lattice(12, n_states=40, avg_degree=4.0, vocab=47, width=4, span=3),
+        "beta_layered120": synth.layered_lattice(13, n_states=120, avg_degree=6.0, vocab=47, width=6, span=4),
+        "beta_edit": synth.edit_lattice([10, 11, 12], [20, 21, 22, 23], vocab=47, seed=5),
+    }
+    for name, lat in cases.items():
+        sc, theta = beta_scorer(lat.vocab, seed=len(name))
+        em, tr = lat.dense()
+        tr_t = torch.from_numpy(tr)
+        with torch.no_grad():
+            b_serial = sc.compute_beta_per_sample(tr_t).numpy().astype(np.float32)
+            sc.set_masks(emission=torch.from_numpy(em)[None], transition=tr_t[None])
+            sc.set_k(2)
+            b_par = sc.compute_beta().numpy().astype(np.float32)
+        assert b_par.shape[0] == 2 and np.array_equal(b_par[0], b_par[1])
+        save(
+            name + ".npz",
+            theta=theta,
+            beta_per_sample=b_serial,
+            beta_parallel=b_par[0],
+            **sc._probe_weights,
+            **lattice_arrays(lat),
+        )
+
+    # The parallel-arc quirk: two labels between one state pair.
+    # states: 0 -bos-> 1 ; 1 -{6,7}-> 2 (parallel) ; 1 -8-> 3 ; 2 -9-> 4 ; 3 -10-> 4 ; 4 -eos-> 5(sink)
+    V = 16
+    src = [0, 1, 1, 1, 2, 3, 4]
+    lab = [BOS, 6, 7, 8, 9, 10, EOS]
+    dst = [1, 2, 2, 3, 4, 4, 5]
+    lat = synth._finish(6, V, src, lab, dst)
+    sc, theta = beta_scorer(V, seed=3)
+    em, tr = lat.dense()
+    with torch.no_grad():
+        b_serial = sc.compute_beta_per_sample(torch.from_numpy(tr)).numpy().astype(np.float32)
+        sc.set_masks(emission=torch.from_numpy(em)[None], transition=torch.from_numpy(tr)[None])
+        sc.set_k(1)
+        b_par = sc.compute_beta().numpy().astype(np.float32)[0]
+    save("beta_parallel_arc_quirk.npz", theta=theta, beta_per_sample=b_serial, beta_parallel=b_par, **sc._probe_weights, **lattice_arrays(lat))
+
+
+def make_gather():
+    V = 24
+    lats = [
+        synth.layered_lattice(21, n_states=18, avg_degree=3.0, vocab=V, width=3, span=2),
+        synth.layered_lattice(22, n_states=30, avg_degree=4.0, vocab=V, width=4, span=3),
+        synth.edit_lattice([10, 11], [12, 13, 14], vocab=V, seed=9),
+    ]
+    rng = np.random.default_rng(77)
+    out = {}
+    for tag, pad_id in (("pad0", 0), ("pad7", 7)):
+        em, tr = synth.collate_dense([l.dense() for l in lats], pad=pad_id)
+        K = 3
+        sc = FSAMaskScorer(hid_dim=4, vocab_size=V, pad=PAD, bos=BOS, eos=EOS, max_length=20)
+        sc.set_masks(emission=torch.from_numpy(em), transition=torch.from_numpy(tr))
+        sc.set_k(K)
+        assert sc.transition_k.shape == (len(lats) * K, em.shape[1], V)
+        N = len(lats) * K
+        # random (state, label) pairs on real rows of each lattice (row < n_rows)
+        reps = 40
+        states = np.zeros((reps, N), dtype=np.int64)
+        labels = rng.integers(0, V, size=(reps, N)).astype(np.int64)
+        for n in range(N):
+            states[:, n] = rng.integers(0, lats[n // K].n_rows, size=reps)
+        nxt = np.zeros_like(states)
+        masks_short = np.zeros((reps, N, V), dtype=np.float32)
+        masks_long = np.zeros((reps, N, V), dtype=np.float32)
+        for r in range(reps):
+            st = torch.from_numpy(states[r])
+            lb = torch.from_numpy(labels[r])
+            nxt[r] = sc.update_fsa_state(lb, st).numpy()
+            masks_short[r] = sc.mask_out_invalid(lb, {"state": st, "length": 5}).numpy()
+            masks_long[r] = sc.mask_out_invalid(lb, {"state": st, "length": 21}).numpy()
+        out.update(
+            {
+                f"{tag}_emission": em,
+                f"{tag}_transition": tr,
+                f"{tag}_states": states,
+                f"{tag}_labels": labels,
+                f"{tag}_next": nxt,
+                f"{tag}_mask_len5": masks_short,
+                f"{tag}_mask_len21": masks_long,
+            }
+        )
+    out["K"] = np.int64(3)
+    out["max_length"] = np.int64(20)
+    out["n_rows"] = np.array([l.n_rows for l in lats], dtype=np.int64)
+    save("gather.npz", **out)
+
+
+def make_sampler_and_iwae():
+    V = 24
+    lats = [
+        synth.layered_lattice(31, n_states=20, avg_degree=3.0, vocab=V, width=3, span=2),
+        synth.edit_lattice([10, 11, 12], [13, 14], vocab=V, seed=4),
+    ]
+    em, tr = synth.collate_dense([l.dense() for l in lats], pad=PAD)
+    B, K = len(lats), 8
+    sc = FSAMaskScorer(hid_dim=4, vocab_size=V, pad=PAD, bos=BOS, eos=EOS, max_length=48)
+    sampler = Sampler(sc)
+    sampler.set_masks(transition=torch.from_numpy(tr), emission=torch.from_numpy(em))
+    sampler.set_k(K)
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        log_q, samples = sampler.sample(B * K)
+        stripped = sampler.stripping_pad(samples)
+    save(
+        "sampler.npz",
+        emission=em,
+        transition=tr,
+        K=np.int64(K),
+        max_length=np.int64(48),
+        log_q=log_q.numpy().astype(np.float32),
+        samples=samples.numpy(),
+        stripped=stripped.numpy(),
+    )
+
+    # IWAE with a WFST (per-mark) unnormalised model
+    torch.manual_seed(5)
+    theta_mod = torch.nn.Embedding(V, 1)
+    with torch.no_grad():
+        theta_mod.weight.copy_(torch.randn(V, 1) * 0.5 - 1.0)
+    wfst = WFSTScorer(PAD, BOS, EOS, theta_mod)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        log_marg, log_q2, samples2, log_w = Estimators.iwae(sampler, wfst, B, K, 0, None)
+        seqs = torch.from_numpy(np.random.default_rng(3).integers(0, V, size=(6, 11)))
+        wscore = wfst.wfst_score(seqs)
+    save(
+        "iwae.npz",
+        emission=em,
+        transition=tr,
+        K=np.int64(K),
+        theta=theta_mod.weight.detach().numpy().reshape(-1).astype(np.float32),
+        log_marginal=log_marg.numpy().astype(np.float32),
+        log_q=log_q2.numpy().astype(np.float32),
+        samples=samples2.numpy(),
+        log_w=log_w.numpy().astype(np.float32),
+        wfst_seqs=seqs.numpy(),
+        wfst_score=wscore.numpy().astype(np.float32),
+    )
+
+
+class _GatherProbe(StaticRNNScorer):
+    """evaluate_seq_with_temp on supplied scores: the RNN (get_seqs) is replaced
+    by a table lookup; everything downstream is the reference's own code."""
+
+    def __init__(self, V, max_length, locally_normalized, label_smoothing):
+        self.bidirectional = False
+        CompositeScorer.__init__(
+            self, 4, V, activation=None, pad=PAD, bos=BOS, eos=EOS, max_length=max_length, num_hidden_states=1
+        )
+        self.simple_sum = False
+        self.right_to_left = False
+        self.locally_normalized = locally_normalized
+        self.label_smoothing = label_smoothing
+        self.bptt_warning = True
+        self._scores = None
+
+    def get_seqs(self, sequence, **kwargs):
+        return self._scores, None
+
+
+def make_evalseq():
+    V, N, T = 20, 6, 9
+    rng = np.random.default_rng(8)
+    seqs = np.full((N, T), PAD, dtype=np.int64)
+    for n in range(N):
+        L = int(rng.integers(2, T - 1))
+        seqs[n, :L] = rng.integers(3, V, size=L)
+        seqs[n, L] = EOS
+    seqs[0, :] = rng.integers(3, V, size=T)  # a row that never ends (hits has_to_end masks)
+    scores = rng.normal(0, 1.5, size=(N, T, V)).astype(np.float32)
+    out = {"seqs": seqs, "scores": scores}
+    for tag, (maxlen, norm, smooth, training, temp) in {
+        "norm_eval": (30, True, 0.0, False, 1.0),
+        "norm_eval_temp": (30, True, 0.0, False, 0.7),
+        "norm_eval_short": (5, True, 0.0, False, 1.0),
+        "raw_eval": (30, False, 0.0, False, 1.0),
+        "norm_train_smooth": (30, True, 0.1, True, 1.0),
+    }.items():
+        pr = _GatherProbe(V, maxlen, norm, smooth)
+        pr.train(training)
+        pr._scores = torch.from_numpy(scores)
+        with torch.no_grad():
+            val = pr.evaluate_seq_with_temp(torch.from_numpy(seqs), temp=temp)
+        out[tag] = val.numpy().astype(np.float32)
+        out[tag + "_cfg"] = np.array([maxlen, int(norm), smooth, int(training), temp], dtype=np.float64)
+    save("evalseq.npz", **out)
+
+
+if __name__ == "__main__":
+    make_beta()
+    make_gather()
+    make_sampler_and_iwae()
+    make_evalseq()

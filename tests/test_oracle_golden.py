@@ -1,0 +1,169 @@
+"""Pins the CPU oracle (oracle/) against the fixtures produced from the real
+reference by tests/golden/make_golden.py.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from nfst_amd import synth
+
+PAD, BOS, EOS = synth.PAD, synth.BOS, synth.EOS
+BETA_CASES = ["beta_layered12", "beta_layered40", "beta_layered120", "beta_edit", "beta_parallel_arc_quirk"]
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", BETA_CASES)
+def test_dense_to_arcs_matches_fixture(golden_dir, name):
+    d = load(golden_dir, name)
+    src, label, dst, w = O.dense_to_arcs(d["emission"], d["transition"])
+    assert w is None
+    assert np.array_equal(src, d["src"]) and np.array_equal(label, d["label"]) and np.array_equal(dst, d["dst"])
+
+
+@pytest.mark.parametrize("name", BETA_CASES)
+def test_beta_matches_reference_per_sample(golden_dir, name):
+    """log beta of compute_beta_per_sample (scorers.py:692-751), all states."""
+    d = load(golden_dir, name)
+    src, label, dst, _ = O.dense_to_arcs(d["emission"], d["transition"])
+    theta = d["theta"].astype(np.float64)
+    r = O.forward_backward(d["transition"].shape[0], src, dst, theta[label])
+    ref = np.log(d["beta_per_sample"].astype(np.float64))
+    reach = np.isfinite(r["logbeta"])
+    # the reference also fills rows that are unreachable from 0; compare reachable rows
+    assert reach[0]
+    assert np.max(np.abs(r["logbeta"][reach] - ref[reach])) < 5e-6
+    assert abs(r["logZ"] - ref[0]) < 5e-6
+
+
+@pytest.mark.parametrize("name", BETA_CASES)
+def test_alpha_posterior_identities(golden_dir, name):
+    d = load(golden_dir, name)
+    src, label, dst, _ = O.dense_to_arcs(d["emission"], d["transition"])
+    n_rows = d["transition"].shape[0]
+    r = O.forward_backward(n_rows, src, dst, d["theta"].astype(np.float64)[label])
+    sink = n_rows - 1
+    assert abs(r["logalpha"][sink] - r["logZ"]) < 1e-9  # Z from alpha == Z from beta
+    post = r["posterior"]
+    nonloop = src != dst
+    assert abs(post[(src == 0) & nonloop].sum() - 1.0) < 1e-9  # flow out of the start
+    assert abs(post[(dst == sink) & nonloop].sum() - 1.0) < 1e-9  # flow into the sink
+    # flow conservation at every inner state
+    inflow = np.bincount(dst[nonloop], weights=post[nonloop], minlength=n_rows)
+    outflow = np.bincount(src[nonloop], weights=post[nonloop], minlength=n_rows)
+    inner = np.ones(n_rows, bool); inner[0] = False; inner[sink] = False
+    assert np.max(np.abs(inflow[inner] - outflow[inner])) < 1e-9
+
+
+@pytest.mark.parametrize("name", BETA_CASES)
+def test_dense_frontier_matches_reference_parallel(golden_dir, name):
+    """compute_beta_parallel (scorers.py:753-856) incl. the parallel-arc quirk."""
+    d = load(golden_dir, name)
+    beta, iters = O.beta_dense_frontier(d["transition"], d["emb"], d["Wx"], d["Wh"], d["W"], d["bias"])
+    ref = d["beta_parallel"]
+    assert iters > 1
+    assert np.array_equal(beta == 0, ref == 0)
+    nz = ref != 0
+    assert np.max(np.abs(beta[nz] / ref[nz] - 1.0)) < 2e-5
+
+
+def test_parallel_arc_quirk_documented(golden_dir):
+    d = load(golden_dir, "beta_parallel_arc_quirk")
+    assert d["beta_parallel"][0] == 0 and d["beta_parallel"][1] == 0  # quirk: ancestors lose their mass
+    assert d["beta_per_sample"][0] > 0
+
+
+@pytest.mark.parametrize("tag", ["pad0", "pad7"])
+def test_state_advance_and_masks(golden_dir, tag):
+    d = load(golden_dir, "gather")
+    K = int(d["K"]); maxlen = int(d["max_length"])
+    tr_k = O.expand_k(d[f"{tag}_transition"], K)
+    em_k = O.expand_k(d[f"{tag}_emission"], K)
+    V = tr_k.shape[2]
+    for r in range(d[f"{tag}_states"].shape[0]):
+        st, lb = d[f"{tag}_states"][r], d[f"{tag}_labels"][r]
+        assert np.array_equal(O.update_fsa_state(tr_k, lb, st), d[f"{tag}_next"][r])
+        for L, key in ((5, "mask_len5"), (21, "mask_len21")):
+            got = O.mask_out_invalid(em_k, lb, st, L, maxlen, PAD, BOS, EOS)
+            assert np.array_equal(got, d[f"{tag}_{key}"][r])
+
+
+def test_sampler_traces_are_accepting_paths(golden_dir):
+    """Every reference sample is an accepting path and its log q is
+    -sum log(out-degree) (uniform FSAMaskScorer proposal)."""
+    d = load(golden_dir, "sampler")
+    K = int(d["K"])
+    samples, log_q = d["samples"], d["log_q"]
+    B = d["emission"].shape[0]
+    for b in range(B):
+        src, label, dst, _ = O.dense_to_arcs(d["emission"][b], d["transition"][b])
+        n_rows = d["transition"][b].shape[0]
+        outdeg = np.bincount(src[src != dst], minlength=n_rows).astype(np.float64)
+        # score of arc = -log outdeg(src): path score == log q of the uniform proposal
+        score = -np.log(np.maximum(outdeg[src], 1.0))
+        marks = samples[b * K:(b + 1) * K].astype(np.int32)
+        # the sampler consumes bos implicitly (inp0 = bos, scorers.py:230-231): prepend it
+        marks = np.concatenate([np.full((K, 1), BOS, np.int32), marks], axis=1)
+        tot, end = O.score_paths(n_rows, src, label, dst, score, marks)
+        sinks = [s for s in range(n_rows) if outdeg[s] == 0 and np.any(dst == s)]
+        assert all(e in sinks for e in end)
+        # bos arc has out-degree 1 -> contributes 0
+        assert np.max(np.abs(tot - log_q[b * K:(b + 1) * K])) < 1e-5
+    assert np.array_equal(O.stripping_pad(samples, PAD), d["stripped"])
+
+
+def test_iwae_and_wfst_score(golden_dir):
+    d = load(golden_dir, "iwae")
+    theta = d["theta"]
+    assert np.max(np.abs(O.wfst_score(theta, d["wfst_seqs"], PAD) - d["wfst_score"])) < 1e-5
+    B, K, T = d["samples"].shape
+    stripped = O.stripping_pad(d["samples"].reshape(B * K, T), PAD)
+    log_p = O.wfst_score(theta, stripped, PAD).reshape(B, K)
+    lm, log_w = O.iwae(log_p, d["log_q"])
+    assert np.max(np.abs(log_w - d["log_w"])) < 1e-5
+    assert np.max(np.abs(lm - d["log_marginal"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["norm_eval", "norm_eval_temp", "norm_eval_short", "raw_eval", "norm_train_smooth"])
+def test_evaluate_seq_arithmetic(golden_dir, tag):
+    d = load(golden_dir, "evalseq")
+    maxlen, norm, smooth, training, temp = d[tag + "_cfg"]
+    got = O.evaluate_seq(d["scores"], d["seqs"], PAD, BOS, EOS, int(maxlen), temp=float(temp),
+                         normalize=bool(norm), training=bool(training), smoothing=float(smooth))
+    ref = d[tag].astype(np.float64)
+    both_inf = np.isinf(ref) & np.isinf(got) & (np.sign(ref) == np.sign(got))
+    both_nan = np.isnan(ref) & np.isnan(got)
+    ok = both_inf | both_nan | (np.abs(got - ref) <= 2e-5 * np.maximum(1.0, np.abs(ref)))
+    assert ok.all(), (got, ref)
+
+
+def test_oracle_rejects_cycles_and_double_sinks():
+    # 0 -> 1 -> 2 -> 1 (cycle)
+    with pytest.raises(O.OracleError):
+        O.forward_backward(4, np.array([0, 1, 2, 2], np.int32), np.array([1, 2, 1, 3], np.int32), np.zeros(4))
+    # two states without out arcs
+    with pytest.raises(O.OracleError):
+        O.forward_backward(3, np.array([0, 0], np.int32), np.array([1, 2], np.int32), np.zeros(2))
+
+
+def test_viterbi_and_sampling_consistency():
+    lat = synth.layered_lattice(5, n_states=60, avg_degree=4.0, vocab=32, width=5, span=3)
+    theta = synth.label_scores(1, 32)
+    score = theta[lat.label].astype(np.float64)
+    r = O.forward_backward(lat.n_rows, lat.src, lat.dst, score)
+    best, path, arcs = O.viterbi(lat.n_rows, lat.src, lat.label, lat.dst, theta[lat.label], 200)
+    assert path[0] == BOS and path[-1] == EOS
+    assert abs(best - score[arcs].sum()) < 1e-4 and best <= r["logZ"] + 1e-6
+    rng = np.random.default_rng(0)
+    K, T = 4000, 80
+    s = O.sample_paths(lat.n_rows, lat.src, lat.label, lat.dst, score, r["logbeta"], rng.random((K, T)), PAD)
+    # exact posterior proposal: log q(path) == path score - log Z for every sample (zero-variance IWAE)
+    for k in range(0, K, 400):
+        a = s["arcs"][k, : s["lengths"][k]]
+        assert abs(score[a].sum() - r["logZ"] - s["logq"][k]) < 1e-9
+    # empirical arc frequencies approach the posteriors
+    cnt = np.bincount(s["arcs"][s["arcs"] >= 0], minlength=lat.n_arcs) / K
+    assert np.max(np.abs(cnt - r["posterior"])) < 0.05
