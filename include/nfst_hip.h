@@ -1,0 +1,290 @@
+/*
+ * nfst_hip.h -- C ABI of the MI355X (gfx950) lattice engine for nFST.
+ *
+ * Drop-in boundary for the reference's lattice hot path.
+ * The reference (steventan0110/nFST) is pure Python and has no FFI; the entry
+ * points below are what a ctypes binding for that path binds, one per Python
+ * call site it replaces (file:line into /root/reference/src):
+ *
+ *   nfst_pack_dense / nfst_pack_arcs   FSAGRUScorer.set_masks + set_k
+ *                                      (modules/scorers.py:877-918), table format
+ *                                      of get_state_mask_pynini (995-1035) and of
+ *                                      the .npz files (preprocess/tr.py:182-190)
+ *   nfst_backward                      FSAGRUScorer.compute_beta
+ *                                      (scorers.py:692-751, 753-875)
+ *   nfst_forward_backward              exact log-Z / alpha / arc posteriors: the
+ *                                      quantity Estimators.iwae estimates
+ *                                      (modules/estimatros.py:33-44), cf.
+ *                                      JointProb.log_marginalize
+ *                                      (modules/lightning.py:408-440)
+ *   nfst_viterbi                       best_sample of JointProb.forward
+ *                                      (lightning.py:474-479)
+ *   nfst_sample_paths                  Sampler.sample / stateful_sample
+ *                                      (modules/samplers.py:137-335)
+ *   nfst_score_paths                   forced scoring (samplers.py:208-218)
+ *   nfst_step                          FSAGRUScorer.update_fsa_state
+ *                                      (scorers.py:683-690)
+ *   nfst_emission_mask                 FSAGRUScorer.mask_out_invalid
+ *                                      (scorers.py:1037-1054)
+ *   nfst_beta_logits                   beta-logit gather (scorers.py:581-593)
+ *   nfst_gather_label_scores           WFSTScorer (scorers.py:1671-1687)
+ *   nfst_path_logprob                  StaticRNNScorer.evaluate_seq_with_temp
+ *                                      gather (scorers.py:1564-1611),
+ *                                      GPT2Wrapper.forward (transformer.py:45-52)
+ *   nfst_iwae                          Estimators.iwae (estimatros.py:11-44)
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++/torch types.
+ *   - "device" pointers are HIP device memory owned by the caller (the Python
+ *     host side passes torch tensors' data_ptr()); "host" pointers are ordinary
+ *     memory.  The library allocates device memory nowhere and keeps no global
+ *     state; every launch goes to the hipStream_t passed as `stream` (void*).
+ *   - every function returns NFST_OK (0) or a negative error code; the message
+ *     is available from nfst_strerror().  Kernels are never launched on invalid
+ *     shapes: all operands are validated on the host first.
+ *   - state, arc and label indices are int32 and bit-exact with the reference's
+ *     int64 tables; floating point is float32 unless stated (log Z also float64).
+ */
+#ifndef NFST_HIP_H
+#define NFST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFST_ABI_VERSION 1
+
+/* error codes */
+#define NFST_OK 0
+#define NFST_ERR_ARG -1        /* null pointer / bad size */
+#define NFST_ERR_INDEX -2      /* state or label index out of range */
+#define NFST_ERR_CYCLE -3      /* lattice is not acyclic */
+#define NFST_ERR_SINK -4       /* not exactly one final (sink) state */
+#define NFST_ERR_DETERMINISM -5/* two arcs with the same (state, label) */
+#define NFST_ERR_LIMIT -6      /* lattice exceeds the engine's limits */
+#define NFST_ERR_HIP -7        /* HIP runtime error */
+#define NFST_ERR_NOMEM -8
+#define NFST_ERR_LENGTH -9     /* "ran out of length budget" (samplers.py:299-302) */
+
+/* limits of the LDS-resident kernels */
+#define NFST_MAX_ROWS 8192     /* states per lattice incl. sink (alpha+beta live in LDS) */
+#define NFST_MAX_VOCAB 32768   /* labels are packed in 16 bits of an arc record */
+
+/* per-lattice metadata: NFST_META_WORDS int32 each, see DESIGN.md */
+#define NFST_META_WORDS 16
+#define NFST_META_ROW_OFF 0    /* first row of this lattice in row-indexed arrays */
+#define NFST_META_N_ROWS 1     /* rows of this lattice (S+1; padded rows included) */
+#define NFST_META_ARC_OFF 2    /* first canonical arc */
+#define NFST_META_N_ARCS 3     /* canonical arcs (incl. self loops) */
+#define NFST_META_FWD_OFF 4    /* word offset of the alpha (by-destination) stream */
+#define NFST_META_FWD_STEPS 5
+#define NFST_META_BWD_OFF 6    /* word offset of the beta (by-source) stream */
+#define NFST_META_BWD_STEPS 7
+#define NFST_META_SINK 8       /* sink state id */
+#define NFST_META_N_REACH 9    /* states reachable from 0 */
+#define NFST_META_DEPTH 10     /* longest path, in arcs */
+#define NFST_META_DP_OFF 11    /* first non-self-loop arc ordinal (perm arrays) */
+#define NFST_META_N_DP 12      /* non-self-loop arcs */
+#define NFST_META_FWD_WORDS 13
+#define NFST_META_BWD_WORDS 14
+
+/*
+ * A packed batch of lattices.  All pointers are host memory when returned by
+ * the packer and device memory when handed to a kernel entry point (the host
+ * side copies the arrays once; K samples per lattice share them, K is a launch
+ * parameter -- scorers.py:887-918 materialises K copies instead).
+ *
+ * Canonical arrays (user-facing): arcs of the states
+ * reachable from state 0 in (state asc, label asc) order; values bit-exact with
+ * nonzero(emission) / transition.  The sink's pad self loop is included.
+ * Streams (engine-private): level-scheduled arc records, DESIGN.md section 3.
+ */
+typedef struct nfst_batch {
+  int32_t n_lattices;
+  int32_t vocab;
+  int32_t max_rows;        /* max n_rows over the batch */
+  int32_t max_steps;       /* max(fwd_steps, bwd_steps) over the batch */
+  int32_t weighted;        /* arc_w holds the table's float weights */
+  int32_t reserved0;
+  int64_t total_rows;
+  int64_t total_arcs;
+  int64_t total_dp_arcs;
+  int64_t fwd_words;
+  int64_t bwd_words;
+  const int32_t *meta;       /* [n_lattices * NFST_META_WORDS] */
+  const int32_t *row_ptr;    /* [total_rows + n_lattices] absolute arc indices */
+  const int32_t *arc_src;    /* [total_arcs] */
+  const int32_t *arc_dst;    /* [total_arcs] */
+  const int32_t *arc_label;  /* [total_arcs] */
+  const float *arc_w;        /* [total_arcs] or NULL */
+  const uint32_t *fwd_stream;/* [fwd_words] */
+  const uint32_t *bwd_stream;/* [bwd_words] */
+  const int32_t *fwd_perm;   /* [total_dp_arcs] stream ordinal -> canonical arc */
+  const int32_t *bwd_perm;   /* [total_dp_arcs] */
+} nfst_batch;
+
+const char *nfst_strerror(int code);
+int nfst_abi_version(void);
+/* 1 when a HIP device is usable, 0 otherwise (never an error) */
+int nfst_device_available(void);
+
+/* ---------------------------------------------------------------- packing (host) */
+typedef struct nfst_packed nfst_packed; /* opaque, owns host arrays */
+
+/* pack options; zero-initialise for defaults */
+typedef struct nfst_pack_opts {
+  int32_t n_threads;       /* host threads over lattices (0 = hardware) */
+  int32_t max_step_words;  /* a step never exceeds this many stream words (0 = 2048) */
+  int32_t lanes_policy;    /* 0 = latency (fill the waves), 1 = throughput (few lanes/state) */
+  int32_t sweep_waves;     /* waves per sweep direction assumed by policy 0 (0 = 4) */
+} nfst_pack_opts;
+
+/*
+ * Dense tables of the reference (scorers.py:995-1035; collated batches as in
+ * util/dataset_reader.py:175-186): emission [B, n_rows, V] as uint8 bool
+ * (emission_is_float = 0) or float32 log weight with -inf for "no arc"
+ * (emission_is_float = 1); transition [B, n_rows, V] int64.  Rows that cannot be
+ * reached from state 0 (collate padding, the machine's old final state) are
+ * ignored.  Host pointers.  On success *out owns the packed batch.
+ * err_lattice (may be NULL) receives the index of the offending lattice.
+ */
+int nfst_pack_dense(const void *emission, int emission_is_float, const int64_t *transition,
+                    int32_t n_lattices, int32_t n_rows, int32_t vocab,
+                    const nfst_pack_opts *opts, nfst_packed **out, int32_t *err_lattice);
+
+/*
+ * Arc lists (a CSR/COO sidecar of the same lattices): lattice b owns arcs
+ * [arc_off[b], arc_off[b+1]) sorted by (src, label); n_rows[b] rows each.
+ * arc_w may be NULL.  Host pointers.
+ */
+int nfst_pack_arcs(const int32_t *n_rows, const int64_t *arc_off, const int32_t *src,
+                   const int32_t *label, const int32_t *dst, const float *arc_w,
+                   int32_t n_lattices, int32_t vocab, const nfst_pack_opts *opts,
+                   nfst_packed **out, int32_t *err_lattice);
+
+/* view of the arrays owned by a packed batch (host pointers, valid until free) */
+int nfst_packed_view(const nfst_packed *p, nfst_batch *view);
+void nfst_packed_free(nfst_packed *p);
+
+/* ---------------------------------------------------------------- kernels (device) */
+
+/* bytes of dynamic LDS the sweep kernels need for this batch (informational) */
+int64_t nfst_lds_bytes(const nfst_batch *lat);
+
+/*
+ * Arc scores.  The log weight of canonical arc a of lattice b is
+ *     theta[(theta_stride * b) + label[a]]  (+ arc_w[a] if the batch is weighted)
+ *                                          (+ arc_scores[a] if arc_scores != NULL)
+ * theta: device float32 [V] (theta_stride = 0, one table for the batch, the
+ * WFSTScorer case) or [B, V] (theta_stride = V).  arc_scores: device float32
+ * [total_arcs] in canonical order, or NULL.
+ */
+typedef struct nfst_scores {
+  const float *theta;
+  int64_t theta_stride;
+  const float *arc_scores;
+} nfst_scores;
+
+/*
+ * Backward (beta) sweep: log beta[row] for every row (float32, -inf for rows
+ * unreachable from 0), log Z = log beta[start] per lattice.  Any output may be
+ * NULL.  beta_me (optional) receives the raw (mantissa, exponent) pairs, 2
+ * float32 words per row, consumed by nfst_sample_paths.
+ * Replaces FSAGRUScorer.compute_beta (scorers.py:858-875); semantics follow
+ * compute_beta_per_sample (692-751) with Wh = 0.
+ */
+int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta,
+                  double *logz64, float *logz32, float *beta_me, void *stream);
+
+/*
+ * Full forward-backward: alpha and beta sweeps, log Z and arc posteriors
+ * posterior[a] = exp(alpha[src] + score + beta[dst] - log Z) in canonical arc
+ * order (= d log Z / d score[a]); grad_theta (optional, [B, V] float32) receives the
+ * posteriors summed per label (d log Z / d theta[b, l]).
+ */
+int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, float *logalpha,
+                          float *logbeta, double *logz64, float *logz32, float *posterior,
+                          float *grad_theta, float *beta_me, void *stream);
+
+/*
+ * Viterbi: best[b] = max path score (float32), paths [B, max_len] int32 labels
+ * of the best path (bos .. eos) padded with `pad`, lengths [B]; path_arcs
+ * (optional) canonical arc ids, -1 padded.  Ties keep the smallest label.
+ */
+int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, int32_t *paths,
+                 int32_t *path_arcs, int32_t *lengths, int32_t max_len, int32_t pad,
+                 void *stream);
+
+/*
+ * Exact posterior path sampling: K walks per lattice from state 0; at state s
+ * arc a is taken with probability exp(score[a] + beta[dst] - beta[s]), chosen by
+ * inverse CDF over the state's arcs in label order from uniforms [B, K, max_len]
+ * (device float32 in [0,1)); if uniforms is NULL a Philox4x32-10 stream keyed by
+ * (seed, walk, step) is used.  paths [B, K, max_len] labels padded with `pad`,
+ * path_arcs (optional) canonical arc ids, lengths [B, K], logq [B, K] =
+ * path score - log Z.  status (device int32, one word, zeroed by the caller)
+ * becomes NFST_ERR_LENGTH if a walk does not reach the sink within max_len.
+ */
+int nfst_sample_paths(const nfst_batch *lat, const nfst_scores *scores, const float *beta_me,
+                      const double *logz64, int32_t k, int32_t max_len, const float *uniforms,
+                      uint64_t seed, int32_t pad, int32_t *paths, int32_t *path_arcs,
+                      int32_t *lengths, float *logq, int32_t *status, void *stream);
+
+/*
+ * Forced walk of marks [B, K, max_len] (pad-terminated) from state 0:
+ * path_score [B, K] = sum of arc scores (-inf if a mark has no arc),
+ * end_state [B, K] (0 if the walk fell off the lattice, like the dense gather).
+ */
+int nfst_score_paths(const nfst_batch *lat, const nfst_scores *scores, const int32_t *marks,
+                     int32_t k, int32_t max_len, float *path_score, int32_t *end_state,
+                     void *stream);
+
+/* state' = transition[state, label] for N = B*K walkers (walker n belongs to
+ * lattice n / k); 0 where the arc does not exist.  int64 in/out like the
+ * reference's LongTensors. */
+int nfst_step(const nfst_batch *lat, const int64_t *state, const int64_t *label, int64_t *next,
+              int32_t k, void *stream);
+
+/* out [B*K, V] float32: 0 (or the table's weight) where the walker's state has
+ * an arc with that label, -inf elsewhere.  If inp != NULL (the previously
+ * emitted mark per walker) the legality masks of LeftToRightScorer.mask_out_invalid
+ * (scorers.py:59-83, 314-338) are added in the same pass: bos never, pad only
+ * after eos/pad, and -- when has_to_end -- only eos for walkers that have not
+ * ended: the whole of FSAGRUScorer.mask_out_invalid in one kernel. */
+int nfst_emission_mask(const nfst_batch *lat, const int64_t *state, const int64_t *inp,
+                       int32_t pad, int32_t bos, int32_t eos, int32_t has_to_end, float *out,
+                       int32_t k, void *stream);
+
+/* out [B*K, V] = values[row_off(b) + transition[state, label]] with values a
+ * row-indexed float32 array (beta in the probability domain in the reference,
+ * any row-indexed array here); labels without an arc read row 0 like the dense
+ * gather does. */
+int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *state,
+                     float *out, int32_t k, void *stream);
+
+/* out[a] = theta[(theta_stride * b) + label[a]] (+ arc_w[a]) (+ arc_scores[a]) */
+int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, float *out,
+                             void *stream);
+
+/*
+ * Fused log_softmax + gather + mask-sum over sequences: scores [N, T, V] float32,
+ * marks [N, T] int64, out [N] float32.  Masks are the reference's
+ * (scorers.py:89-134): bos/pad illegal, after eos/pad only pad, beyond
+ * max_length only eos (max_length < 0 disables); the pad column of scores is
+ * zeroed (pad_masking_3d, scorers.py:189-192); positions holding pad contribute
+ * 0.  normalize = 0 skips the log_softmax (self_normalized = False).
+ */
+int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int32_t t,
+                      int32_t vocab, int32_t pad, int32_t bos, int32_t eos, int32_t max_length,
+                      float temp, int32_t normalize, float *out, void *stream);
+
+/* log_w [B,K] = log_p - log_q ; log_marginal [B] = logsumexp_k(log_w) - log K */
+int nfst_iwae(const float *log_p, const float *log_q, int32_t b, int32_t k, float *log_w,
+              float *log_marginal, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFST_HIP_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of ``libnfst_hip.so`` (the C ABI declared in include/nfst_hip.h).
+
+The library is the product: there is no CPU fallback.  If it cannot be loaded
+the import of this module fails with an explicit error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnfst_hip.so")
+
+META_WORDS = 16
+(META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_STEPS, META_BWD_OFF,
+ META_BWD_STEPS, META_SINK, META_N_REACH, META_DEPTH, META_DP_OFF, META_N_DP, META_FWD_WORDS,
+ META_BWD_WORDS) = range(15)
+
+OK = 0
+ERR_LENGTH = -9
+
+
+class NfstError(RuntimeError):
+    def __init__(self, code: int, where: str, lattice: int = -1):
+        self.code = code
+        self.lattice = lattice
+        msg = lib.nfst_strerror(code).decode()
+        if lattice >= 0:
+            msg += f" (lattice {lattice})"
+        super().__init__(f"{where}: {msg} [code {code}]")
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("n_lattices", C.c_int32), ("vocab", C.c_int32), ("max_rows", C.c_int32), ("max_steps", C.c_int32),
+        ("weighted", C.c_int32), ("reserved0", C.c_int32),
+        ("total_rows", C.c_int64), ("total_arcs", C.c_int64), ("total_dp_arcs", C.c_int64),
+        ("fwd_words", C.c_int64), ("bwd_words", C.c_int64),
+        ("meta", C.c_void_p), ("row_ptr", C.c_void_p), ("arc_src", C.c_void_p), ("arc_dst", C.c_void_p),
+        ("arc_label", C.c_void_p), ("arc_w", C.c_void_p), ("fwd_stream", C.c_void_p), ("bwd_stream", C.c_void_p),
+        ("fwd_perm", C.c_void_p), ("bwd_perm", C.c_void_p),
+    ]
+
+
+class Scores(C.Structure):
+    _fields_ = [("theta", C.c_void_p), ("theta_stride", C.c_int64), ("arc_scores", C.c_void_p)]
+
+
+class PackOpts(C.Structure):
+    _fields_ = [("n_threads", C.c_int32), ("max_step_words", C.c_int32), ("lanes_policy", C.c_int32),
+                ("sweep_waves", C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m nfst_amd.build` (hipcc --offload-arch=gfx950). "
+            "nfst_amd has no CPU fallback."
+        )
+    l = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    BP, SP = C.POINTER(Batch), C.POINTER(Scores)
+    sig = {
+        "nfst_strerror": (C.c_char_p, [C.c_int]),
+        "nfst_abi_version": (C.c_int, []),
+        "nfst_device_available": (C.c_int, []),
+        "nfst_pack_dense": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
+        "nfst_pack_arcs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
+        "nfst_packed_view": (C.c_int, [vp, BP]),
+        "nfst_packed_free": (None, [vp]),
+        "nfst_lds_bytes": (i64, [BP]),
+        "nfst_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp]),
+        "nfst_forward_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "nfst_viterbi": (C.c_int, [BP, SP, vp, vp, vp, vp, i32, i32, vp]),
+        "nfst_sample_paths": (C.c_int, [BP, SP, vp, vp, i32, i32, vp, u64, i32, vp, vp, vp, vp, vp, vp]),
+        "nfst_score_paths": (C.c_int, [BP, SP, vp, i32, i32, vp, vp, vp]),
+        "nfst_step": (C.c_int, [BP, vp, vp, vp, i32, vp]),
+        "nfst_emission_mask": (C.c_int, [BP, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+        "nfst_beta_logits": (C.c_int, [BP, vp, vp, vp, i32, vp]),
+        "nfst_gather_label_scores": (C.c_int, [BP, SP, vp, vp]),
+        "nfst_path_logprob": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]),
+        "nfst_iwae": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(l, name)  # AttributeError here = the library does not match the header
+        fn.restype = res
+        fn.argtypes = args
+    return l, list(sig)
+
+
+lib, EXPORTS = _load()
+if lib.nfst_abi_version() != 1:
+    raise ImportError("libnfst_hip.so ABI version mismatch; rebuild with `python -m nfst_amd.build --force`")
+
+
+def check(code: int, where: str, lattice: int = -1) -> None:
+    if code != OK:
+        raise NfstError(code, where, lattice)

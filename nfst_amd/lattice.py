@@ -1,0 +1,213 @@
+"""LatticeBatch: a batch of nFST lattices packed once, shared by all K samples.
+
+Host-side mirror of ``FSAGRUScorer.set_masks`` / ``set_k``
+(/root/reference/src/modules/scorers.py:877-918).  The reference keeps the dense
+``emission``/``transition`` tables ``[B, S+1, V]`` and materialises K copies of
+them; here the tables are scanned once into canonical CSR arrays plus two
+level-scheduled arc streams (include/nfst_hip.h) that the
+HIP kernels consume.  torch is used for device memory only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+def _host(a, dtype) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _view(ptr, n, ctype, dtype) -> np.ndarray:
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype, copy=True)
+
+
+class LatticeBatch:
+    """Packed lattices.  Tensors live on ``self.device``; ``meta`` is also kept on
+    the host (numpy) because shapes and offsets are needed to size outputs."""
+
+    _FIELDS = ("meta", "row_ptr", "arc_src", "arc_dst", "arc_label", "arc_w", "fwd_stream", "bwd_stream",
+               "fwd_perm", "bwd_perm")
+
+    def __init__(self, header: dict, tensors: dict):
+        self._h = dict(header)
+        self._t = dict(tensors)
+        self.meta_host = self._t["meta"].detach().cpu().numpy().reshape(-1, _lib.META_WORDS).copy()
+        self._struct = None
+
+    # ---------------------------------------------------------------- construction
+    @staticmethod
+    def _opts(n_threads=0, max_step_words=0, lanes_policy=0, sweep_waves=0):
+        return _lib.PackOpts(int(n_threads), int(max_step_words), int(lanes_policy), int(sweep_waves))
+
+    @classmethod
+    def _from_handle(cls, handle, device) -> "LatticeBatch":
+        try:
+            v = _lib.Batch()
+            check(lib.nfst_packed_view(handle, C.byref(v)), "nfst_packed_view")
+            B = v.n_lattices
+            arrs = {
+                "meta": _view(v.meta, B * _lib.META_WORDS, C.c_int32, np.int32),
+                "row_ptr": _view(v.row_ptr, v.total_rows + B, C.c_int32, np.int32),
+                "arc_src": _view(v.arc_src, v.total_arcs, C.c_int32, np.int32),
+                "arc_dst": _view(v.arc_dst, v.total_arcs, C.c_int32, np.int32),
+                "arc_label": _view(v.arc_label, v.total_arcs, C.c_int32, np.int32),
+                "arc_w": _view(v.arc_w, v.total_arcs, C.c_float, np.float32) if v.weighted else None,
+                "fwd_stream": _view(v.fwd_stream, v.fwd_words, C.c_int32, np.int32),
+                "bwd_stream": _view(v.bwd_stream, v.bwd_words, C.c_int32, np.int32),
+                "fwd_perm": _view(v.fwd_perm, v.total_dp_arcs, C.c_int32, np.int32),
+                "bwd_perm": _view(v.bwd_perm, v.total_dp_arcs, C.c_int32, np.int32),
+            }
+            header = {k: int(getattr(v, k)) for k in ("n_lattices", "vocab", "max_rows", "max_steps", "weighted",
+                                                      "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
+                                                      "bwd_words")}
+        finally:
+            lib.nfst_packed_free(handle)
+        tensors = {k: (None if a is None else torch.from_numpy(a)) for k, a in arrs.items()}
+        out = cls(header, tensors)
+        return out.to(device) if device is not None else out
+
+    @classmethod
+    def from_dense(cls, emission, transition, device=None, **pack_opts) -> "LatticeBatch":
+        """emission ``[B, S+1, V]`` bool (or float log weights, -inf = no arc) and
+        transition ``[B, S+1, V]`` int64, as ``set_masks`` receives them
+        (scorers.py:877-885; collated as in util/dataset_reader.py:175-186)."""
+        if device is None and isinstance(transition, torch.Tensor) and transition.is_cuda:
+            device = transition.device
+        is_float = (emission.dtype.is_floating_point if isinstance(emission, torch.Tensor)
+                    else np.issubdtype(np.asarray(emission).dtype, np.floating))
+        em = _host(emission, np.float32 if is_float else np.bool_)
+        tr = _host(transition, np.int64)
+        if em.ndim != 3 or tr.shape != em.shape:
+            raise ValueError("emission and transition must both be [B, S+1, V]")
+        B, R, V = tr.shape
+        opts = cls._opts(**pack_opts)
+        handle = C.c_void_p()
+        bad = C.c_int32(-1)
+        rc = lib.nfst_pack_dense(em.ctypes.data, 1 if is_float else 0, tr.ctypes.data, B, R, V, C.byref(opts),
+                                 C.byref(handle), C.byref(bad))
+        check(rc, "nfst_pack_dense", bad.value)
+        return cls._from_handle(handle, device)
+
+    @classmethod
+    def from_arcs(cls, n_rows, arc_off, src, label, dst, vocab: int, arc_w=None, device=None,
+                  **pack_opts) -> "LatticeBatch":
+        """Arc lists sorted by (src, label); lattice b owns arcs [arc_off[b], arc_off[b+1])."""
+        n_rows = _host(n_rows, np.int32)
+        arc_off = _host(arc_off, np.int64)
+        src, label, dst = _host(src, np.int32), _host(label, np.int32), _host(dst, np.int32)
+        w = None if arc_w is None else _host(arc_w, np.float32)
+        B = n_rows.shape[0]
+        if arc_off.shape[0] != B + 1 or not (src.shape == label.shape == dst.shape) or arc_off[-1] != src.shape[0]:
+            raise ValueError("inconsistent arc list shapes")
+        opts = cls._opts(**pack_opts)
+        handle = C.c_void_p()
+        bad = C.c_int32(-1)
+        rc = lib.nfst_pack_arcs(n_rows.ctypes.data, arc_off.ctypes.data, src.ctypes.data, label.ctypes.data,
+                                dst.ctypes.data, None if w is None else w.ctypes.data, B, int(vocab),
+                                C.byref(opts), C.byref(handle), C.byref(bad))
+        check(rc, "nfst_pack_arcs", bad.value)
+        return cls._from_handle(handle, device)
+
+    @classmethod
+    def from_synth(cls, lattices: Sequence, device=None, **pack_opts) -> "LatticeBatch":
+        from . import synth
+        n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lattices)
+        return cls.from_arcs(n_rows, arc_off, src, label, dst, lattices[0].vocab, arc_w=w, device=device, **pack_opts)
+
+    # ---------------------------------------------------------------- placement
+    def to(self, device) -> "LatticeBatch":
+        device = torch.device(device)
+        t = {k: (None if v is None else v.to(device)) for k, v in self._t.items()}
+        return LatticeBatch(self._h, t)
+
+    @property
+    def device(self) -> torch.device:
+        return self._t["meta"].device
+
+    # ---------------------------------------------------------------- accessors
+    def __getattr__(self, name):
+        if name in ("_h", "_t"):
+            raise AttributeError(name)
+        if name in self._h:
+            return self._h[name]
+        if name in self._t:
+            return self._t[name]
+        raise AttributeError(name)
+
+    @property
+    def n_rows(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_N_ROWS]
+
+    @property
+    def row_off(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_ROW_OFF]
+
+    @property
+    def arc_off(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_ARC_OFF]
+
+    @property
+    def n_arcs(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_N_ARCS]
+
+    @property
+    def n_dp_arcs(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_N_DP]
+
+    @property
+    def depth(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_DEPTH]
+
+    @property
+    def sink(self) -> np.ndarray:
+        return self.meta_host[:, _lib.META_SINK]
+
+    @property
+    def uniform_rows(self) -> bool:
+        return bool(np.all(self.n_rows == self.n_rows[0]))
+
+    def rows_view(self, x: torch.Tensor) -> torch.Tensor:
+        """[total_rows, ...] -> [B, S+1, ...] when every lattice has the same row count."""
+        if not self.uniform_rows:
+            raise ValueError("lattices have different row counts; index with row_off instead")
+        return x.reshape(self.n_lattices, int(self.n_rows[0]), *x.shape[1:])
+
+    def arc_lattice(self) -> torch.Tensor:
+        """int64 [total_arcs]: the lattice each canonical arc belongs to."""
+        reps = torch.from_numpy(self.n_arcs.astype(np.int64))
+        return torch.repeat_interleave(torch.arange(self.n_lattices), reps).to(self.device)
+
+    # ---------------------------------------------------------------- C view
+    def c_struct(self) -> _lib.Batch:
+        """nfst_batch whose pointers are this batch's tensors (device memory)."""
+        if self._struct is None:
+            s = _lib.Batch()
+            for k, v in self._h.items():
+                setattr(s, k, v)
+            for k in self._FIELDS:
+                t = self._t[k]
+                setattr(s, k, None if t is None or t.numel() == 0 else t.data_ptr())
+            self._struct = s
+        return self._struct
+
+    def lds_bytes(self) -> int:
+        return int(lib.nfst_lds_bytes(C.byref(self.c_struct())))
+
+    def algorithmic_bytes(self, mode: str = "forward_backward") -> int:
+        """log-Z only = 8 B/arc + 8 B/state; full
+        forward-backward with arc posteriors = 32 B/arc + 24 B/state."""
+        arcs = int(self.n_dp_arcs.sum())
+        states = int(self.meta_host[:, _lib.META_N_REACH].sum())
+        if mode == "backward":
+            return 8 * arcs + 8 * states
+        return 32 * arcs + 24 * states

@@ -1,0 +1,294 @@
+"""Operators of the lattice engine: thin wrappers that allocate outputs with torch
+and launch the HIP kernels through the C ABI (include/nfst_hip.h) on torch's
+current stream.  There is no CPU implementation: every function raises if the
+batch is not on a HIP device.  Reference call sites replaced are cited per op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .lattice import LatticeBatch
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(lat: LatticeBatch) -> None:
+    if lat.device.type != "cuda":
+        raise RuntimeError("nfst_amd: the lattice engine runs on the MI355X only (no CPU fallback); "
+                           "move the batch with LatticeBatch.to('cuda')")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _scores(lat: LatticeBatch, theta: torch.Tensor, arc_scores: Optional[torch.Tensor]):
+    """nfst_scores + the tensors that must stay alive during the launch."""
+    if theta.dtype != torch.float32 or theta.device != lat.device:
+        theta = theta.to(device=lat.device, dtype=torch.float32)
+    theta = theta.contiguous()
+    if theta.dim() == 1:
+        if theta.shape[0] != lat.vocab:
+            raise ValueError(f"theta must have {lat.vocab} entries")
+        stride = 0
+    elif theta.dim() == 2 and theta.shape == (lat.n_lattices, lat.vocab):
+        stride = lat.vocab
+    else:
+        raise ValueError("theta must be [V] or [B, V]")
+    if arc_scores is not None:
+        arc_scores = arc_scores.to(device=lat.device, dtype=torch.float32).contiguous()
+        if arc_scores.shape != (lat.total_arcs,):
+            raise ValueError(f"arc_scores must be [{lat.total_arcs}] in canonical arc order")
+    return _lib.Scores(theta.data_ptr(), stride, _ptr(arc_scores)), (theta, arc_scores)
+
+
+class BackwardResult(NamedTuple):
+    logbeta: Optional[torch.Tensor]  # [total_rows] float32
+    logz: torch.Tensor  # [B] float32
+    logz64: torch.Tensor  # [B] float64
+    beta_me: Optional[torch.Tensor]  # [total_rows, 2] float32 (mantissa, exponent bits)
+
+
+def backward(lat: LatticeBatch, theta, arc_scores=None, want_logbeta=True, want_me=False) -> BackwardResult:
+    """beta sweep + log Z.  Replaces FSAGRUScorer.compute_beta
+    (/root/reference/src/modules/scorers.py:858-875)."""
+    _need_gpu(lat)
+    sc, keep = _scores(lat, theta, arc_scores)
+    dev = lat.device
+    logbeta = torch.empty(lat.total_rows, dtype=torch.float32, device=dev) if want_logbeta else None
+    z64 = torch.empty(lat.n_lattices, dtype=torch.float64, device=dev)
+    z32 = torch.empty(lat.n_lattices, dtype=torch.float32, device=dev)
+    me = torch.empty((lat.total_rows, 2), dtype=torch.float32, device=dev) if want_me else None
+    check(lib.nfst_backward(C.byref(lat.c_struct()), C.byref(sc), _ptr(logbeta), _ptr(z64), _ptr(z32), _ptr(me),
+                            _stream()), "nfst_backward")
+    return BackwardResult(logbeta, z32, z64, me)
+
+
+class ForwardBackwardResult(NamedTuple):
+    logz: torch.Tensor
+    logz64: torch.Tensor
+    logalpha: Optional[torch.Tensor]
+    logbeta: Optional[torch.Tensor]
+    posterior: Optional[torch.Tensor]  # [total_arcs] canonical order
+    grad_theta: Optional[torch.Tensor]  # [B, V]
+    beta_me: Optional[torch.Tensor]
+
+
+def forward_backward(lat: LatticeBatch, theta, arc_scores=None, want_alpha_beta=True, want_posterior=True,
+                     want_grad_theta=False, want_me=False) -> ForwardBackwardResult:
+    """alpha/beta sweeps, exact log Z and arc posteriors (the quantity the
+    reference only estimates by IWAE, modules/estimatros.py:33-44)."""
+    _need_gpu(lat)
+    sc, keep = _scores(lat, theta, arc_scores)
+    dev = lat.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    la = torch.empty(lat.total_rows, **f32) if want_alpha_beta else None
+    lb = torch.empty(lat.total_rows, **f32) if want_alpha_beta else None
+    z64 = torch.empty(lat.n_lattices, dtype=torch.float64, device=dev)
+    z32 = torch.empty(lat.n_lattices, **f32)
+    post = torch.empty(lat.total_arcs, **f32) if want_posterior else None
+    gth = torch.empty((lat.n_lattices, lat.vocab), **f32) if want_grad_theta else None
+    me = torch.empty((lat.total_rows, 2), **f32) if want_me else None
+    check(lib.nfst_forward_backward(C.byref(lat.c_struct()), C.byref(sc), _ptr(la), _ptr(lb), _ptr(z64), _ptr(z32),
+                                    _ptr(post), _ptr(gth), _ptr(me), _stream()), "nfst_forward_backward")
+    return ForwardBackwardResult(z32, z64, la, lb, post, gth, me)
+
+
+class _LogZ(torch.autograd.Function):
+    """log Z with d log Z / d score = arc posterior."""
+
+    @staticmethod
+    def forward(ctx, lat, theta, arc_scores):
+        need_t = theta.requires_grad
+        need_a = arc_scores is not None and arc_scores.requires_grad
+        r = forward_backward(lat, theta.detach(), None if arc_scores is None else arc_scores.detach(),
+                             want_alpha_beta=False, want_posterior=need_a, want_grad_theta=need_t)
+        ctx.lat = lat
+        ctx.shared_theta = theta.dim() == 1
+        ctx.save_for_backward(r.posterior if need_a else None, r.grad_theta if need_t else None)
+        return r.logz
+
+    @staticmethod
+    def backward(ctx, g):
+        post, gth = ctx.saved_tensors
+        g_theta = g_arc = None
+        if gth is not None:
+            g_theta = gth * g[:, None]
+            if ctx.shared_theta:
+                g_theta = g_theta.sum(dim=0)
+        if post is not None:
+            g_arc = post * g[ctx.lat.arc_lattice()]
+        return None, g_theta, g_arc
+
+
+def log_z(lat: LatticeBatch, theta: torch.Tensor, arc_scores: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable exact log-marginal per lattice, float32 [B]."""
+    return _LogZ.apply(lat, theta, arc_scores)
+
+
+class ViterbiResult(NamedTuple):
+    best: torch.Tensor  # [B] float32
+    paths: torch.Tensor  # [B, max_len] int32, pad-terminated (bos .. eos)
+    arcs: torch.Tensor  # [B, max_len] int32 canonical arc ids, -1 padded
+    lengths: torch.Tensor  # [B] int32
+
+
+def viterbi(lat: LatticeBatch, theta, arc_scores=None, max_len: Optional[int] = None, pad: int = 0) -> ViterbiResult:
+    """Best path per lattice (best_sample of JointProb.forward, modules/lightning.py:474-479)."""
+    _need_gpu(lat)
+    sc, keep = _scores(lat, theta, arc_scores)
+    if max_len is None:
+        max_len = int(lat.depth.max()) + 1
+    dev = lat.device
+    best = torch.empty(lat.n_lattices, dtype=torch.float32, device=dev)
+    paths = torch.empty((lat.n_lattices, max_len), dtype=torch.int32, device=dev)
+    arcs = torch.empty((lat.n_lattices, max_len), dtype=torch.int32, device=dev)
+    lens = torch.empty(lat.n_lattices, dtype=torch.int32, device=dev)
+    check(lib.nfst_viterbi(C.byref(lat.c_struct()), C.byref(sc), _ptr(best), _ptr(paths), _ptr(arcs), _ptr(lens),
+                           int(max_len), int(pad), _stream()), "nfst_viterbi")
+    return ViterbiResult(best, paths, arcs, lens)
+
+
+class SampleResult(NamedTuple):
+    paths: torch.Tensor  # [B, K, max_len] int32 labels, pad-terminated
+    arcs: torch.Tensor  # [B, K, max_len] int32 canonical arc ids
+    lengths: torch.Tensor  # [B, K]
+    logq: torch.Tensor  # [B, K] float32 = path score - log Z
+    logz: torch.Tensor  # [B] float32
+
+
+def sample_paths(lat: LatticeBatch, theta, k: int, arc_scores=None, max_len: Optional[int] = None,
+                 uniforms: Optional[torch.Tensor] = None, seed: int = 0, pad: int = 0,
+                 beta: Optional[BackwardResult] = None) -> SampleResult:
+    """K exact posterior samples per lattice (Sampler.sample, modules/samplers.py:137-335,
+    with the exact posterior as proposal)."""
+    _need_gpu(lat)
+    sc, keep = _scores(lat, theta, arc_scores)
+    if max_len is None:
+        max_len = int(lat.depth.max()) + 1
+    if beta is None or beta.beta_me is None:
+        beta = backward(lat, theta, arc_scores, want_logbeta=False, want_me=True)
+    dev = lat.device
+    B = lat.n_lattices
+    if uniforms is not None:
+        uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+        if uniforms.shape != (B, k, max_len):
+            raise ValueError(f"uniforms must be [{B}, {k}, {max_len}]")
+    paths = torch.empty((B, k, max_len), dtype=torch.int32, device=dev)
+    arcs = torch.empty((B, k, max_len), dtype=torch.int32, device=dev)
+    lens = torch.empty((B, k), dtype=torch.int32, device=dev)
+    logq = torch.empty((B, k), dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.nfst_sample_paths(C.byref(lat.c_struct()), C.byref(sc), _ptr(beta.beta_me), _ptr(beta.logz64), int(k),
+                                int(max_len), _ptr(uniforms), C.c_uint64(seed & (2 ** 64 - 1)), int(pad), _ptr(paths),
+                                _ptr(arcs), _ptr(lens), _ptr(logq), _ptr(status), _stream()), "nfst_sample_paths")
+    st = int(status.item())
+    if st != 0:
+        raise _lib.NfstError(st, "nfst_sample_paths")  # "ran out of length budget" (samplers.py:299-302)
+    return SampleResult(paths, arcs, lens, logq, beta.logz)
+
+
+def score_paths(lat: LatticeBatch, theta, marks: torch.Tensor, arc_scores=None):
+    """Forced walk of marks [B, K, T] (samplers.py:208-218): (path_score [B,K], end_state [B,K])."""
+    _need_gpu(lat)
+    sc, keep = _scores(lat, theta, arc_scores)
+    marks = marks.to(device=lat.device, dtype=torch.int32).contiguous()
+    B, K, T = marks.shape
+    if B != lat.n_lattices:
+        raise ValueError("marks must be [B, K, T]")
+    tot = torch.empty((B, K), dtype=torch.float32, device=lat.device)
+    end = torch.empty((B, K), dtype=torch.int32, device=lat.device)
+    check(lib.nfst_score_paths(C.byref(lat.c_struct()), C.byref(sc), _ptr(marks), K, T, _ptr(tot), _ptr(end),
+                               _stream()), "nfst_score_paths")
+    return tot, end
+
+
+def _walkers(lat: LatticeBatch, x: torch.Tensor, k: int, name: str) -> torch.Tensor:
+    x = x.to(device=lat.device, dtype=torch.int64).contiguous()
+    if x.shape != (lat.n_lattices * k,):
+        raise ValueError(f"{name} must be [B*k] = [{lat.n_lattices * k}]")
+    return x
+
+
+def step(lat: LatticeBatch, state: torch.Tensor, label: torch.Tensor, k: int = 1) -> torch.Tensor:
+    """state' = transition[state, label] (FSAGRUScorer.update_fsa_state, scorers.py:683-690)."""
+    _need_gpu(lat)
+    state, label = _walkers(lat, state, k, "state"), _walkers(lat, label, k, "label")
+    out = torch.empty_like(state)
+    check(lib.nfst_step(C.byref(lat.c_struct()), _ptr(state), _ptr(label), _ptr(out), int(k), _stream()), "nfst_step")
+    return out
+
+
+def emission_mask(lat: LatticeBatch, state: torch.Tensor, k: int = 1, inp: Optional[torch.Tensor] = None,
+                  pad: int = 0, bos: int = 1, eos: int = 2, has_to_end: bool = False) -> torch.Tensor:
+    """[B*k, V] mask of FSAGRUScorer.mask_out_invalid (scorers.py:1037-1054); with
+    ``inp`` the bos/pad/eos legality masks (scorers.py:59-83) are fused in."""
+    _need_gpu(lat)
+    state = _walkers(lat, state, k, "state")
+    if inp is not None:
+        inp = _walkers(lat, inp, k, "inp")
+    out = torch.empty((state.shape[0], lat.vocab), dtype=torch.float32, device=lat.device)
+    check(lib.nfst_emission_mask(C.byref(lat.c_struct()), _ptr(state), _ptr(inp), int(pad), int(bos), int(eos),
+                                 int(bool(has_to_end)), _ptr(out), int(k), _stream()), "nfst_emission_mask")
+    return out
+
+
+def beta_logits(lat: LatticeBatch, values: torch.Tensor, state: torch.Tensor, k: int = 1) -> torch.Tensor:
+    """[B*k, V] = values[transition[state, :]] (GRUScorer beta-logit gather, scorers.py:581-593)."""
+    _need_gpu(lat)
+    state = _walkers(lat, state, k, "state")
+    values = values.to(device=lat.device, dtype=torch.float32).contiguous().reshape(-1)
+    if values.shape[0] != lat.total_rows:
+        raise ValueError("values must be row-indexed [total_rows]")
+    out = torch.empty((state.shape[0], lat.vocab), dtype=torch.float32, device=lat.device)
+    check(lib.nfst_beta_logits(C.byref(lat.c_struct()), _ptr(values), _ptr(state), _ptr(out), int(k), _stream()),
+          "nfst_beta_logits")
+    return out
+
+
+def gather_label_scores(lat: LatticeBatch, theta, arc_scores=None) -> torch.Tensor:
+    """Per-arc log weights in canonical order (WFSTScorer, scorers.py:1671-1687)."""
+    _need_gpu(lat)
+    sc, keep = _scores(lat, theta, arc_scores)
+    out = torch.empty(lat.total_arcs, dtype=torch.float32, device=lat.device)
+    check(lib.nfst_gather_label_scores(C.byref(lat.c_struct()), C.byref(sc), _ptr(out), _stream()),
+          "nfst_gather_label_scores")
+    return out
+
+
+def path_logprob(scores: torch.Tensor, marks: torch.Tensor, pad: int = 0, bos: int = 1, eos: int = 2,
+                 max_length: Optional[int] = None, temp: float = 1.0, normalize: bool = True) -> torch.Tensor:
+    """Fused masks + log_softmax + gather + pad-masked sum over time
+    (StaticRNNScorer.evaluate_seq_with_temp, scorers.py:1564-1611): scores [N,T,V], marks [N,T] -> [N]."""
+    if scores.device.type != "cuda":
+        raise RuntimeError("nfst_amd: path_logprob runs on the MI355X only (no CPU fallback)")
+    scores = scores.to(torch.float32).contiguous()
+    marks = marks.to(device=scores.device, dtype=torch.int64).contiguous()
+    N, T, V = scores.shape
+    if marks.shape != (N, T):
+        raise ValueError("marks must be [N, T]")
+    out = torch.empty(N, dtype=torch.float32, device=scores.device)
+    check(lib.nfst_path_logprob(_ptr(scores), _ptr(marks), N, T, V, int(pad), int(bos), int(eos),
+                                -1 if max_length is None else int(max_length), C.c_float(temp), int(bool(normalize)),
+                                _ptr(out), _stream()), "nfst_path_logprob")
+    return out
+
+
+def iwae(log_p: torch.Tensor, log_q: torch.Tensor):
+    """(log_marginal [B], log_w [B,K]) of Estimators.iwae (modules/estimatros.py:11-44)."""
+    if log_p.device.type != "cuda":
+        raise RuntimeError("nfst_amd: iwae runs on the MI355X only (no CPU fallback)")
+    log_p = log_p.to(torch.float32).contiguous()
+    log_q = log_q.to(device=log_p.device, dtype=torch.float32).contiguous()
+    B, K = log_p.shape
+    log_w = torch.empty_like(log_p)
+    lm = torch.empty(B, dtype=torch.float32, device=log_p.device)
+    check(lib.nfst_iwae(_ptr(log_p), _ptr(log_q), B, K, _ptr(log_w), _ptr(lm), _stream()), "nfst_iwae")
+    return lm, log_w

@@ -1,0 +1,345 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden
+fixtures.  Needs a real MI355X: run with ``pytest -m gpu``.
+
+Tolerances: log Z, log alpha, log beta <= 1e-5 absolute (north_star); posteriors
+<= 2e-6 absolute; state / arc / label indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from nfst_amd import ops, synth, _lib
+from nfst_amd.lattice import LatticeBatch
+
+pytestmark = pytest.mark.gpu
+PAD, BOS, EOS = synth.PAD, synth.BOS, synth.EOS
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert _lib.lib.nfst_device_available() == 1
+    return torch.device("cuda:0")
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def oracle_fb(l, theta, arc_scores=None):
+    sc = theta[l.label].astype(np.float64)
+    if l.weight is not None:
+        sc = sc + l.weight.astype(np.float64)
+    if arc_scores is not None:
+        sc = sc + arc_scores.astype(np.float64)
+    return O.forward_backward(l.n_rows, l.src, l.dst, sc), sc
+
+
+def cmp_rows(got, ref, tol=TOL):
+    got = np.asarray(got, np.float64)
+    inf = np.isneginf(ref)
+    assert np.array_equal(np.isneginf(got), inf)
+    assert np.max(np.abs(got[~inf] - ref[~inf])) <= tol
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name", ["beta_layered12", "beta_layered40", "beta_layered120", "beta_edit",
+                                  "beta_parallel_arc_quirk"])
+def test_beta_matches_reference_fixture(dev, golden_dir, name):
+    """log beta of the reference's compute_beta_per_sample (scorers.py:692-751)."""
+    d = load(golden_dir, name)
+    lat = LatticeBatch.from_dense(d["emission"][None], d["transition"][None], device=dev)
+    r = ops.backward(lat, torch.from_numpy(d["theta"]))
+    got = r.logbeta.cpu().numpy()
+    ref = np.log(d["beta_per_sample"].astype(np.float64))
+    reach = np.isfinite(got)
+    assert reach[0] and reach.sum() == lat.meta_host[0][_lib.META_N_REACH]
+    assert np.max(np.abs(got[reach] - ref[reach])) <= TOL
+    assert abs(float(r.logz64[0]) - ref[0]) <= TOL and abs(float(r.logz[0]) - ref[0]) <= TOL
+    # exp view for legacy consumers (probability domain, like compute_beta returns)
+    assert np.allclose(np.exp(got[reach]), d["beta_per_sample"][reach], rtol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["pad0", "pad7"])
+def test_state_advance_and_masks_bit_exact(dev, golden_dir, tag):
+    d = load(golden_dir, "gather")
+    K, maxlen = int(d["K"]), int(d["max_length"])
+    lat = LatticeBatch.from_dense(d[f"{tag}_emission"], d[f"{tag}_transition"], device=dev)
+    n_rows = d["n_rows"]
+    for r in range(d[f"{tag}_states"].shape[0]):
+        st = torch.from_numpy(d[f"{tag}_states"][r]).to(dev)
+        lb = torch.from_numpy(d[f"{tag}_labels"][r]).to(dev)
+        nxt = ops.step(lat, st, lb, k=K).cpu().numpy()
+        # rows the reference tables hold but that cannot be reached from state 0
+        # (the machine's old final state, collate padding) are not part of the lattice
+        reach = np.array([np.isfinite(x) for x in np.zeros(len(st))])
+        ref = d[f"{tag}_next"][r]
+        em_rows = d[f"{tag}_emission"][np.arange(len(st)) // K, d[f"{tag}_states"][r]]
+        packed_rows = lat.row_ptr.cpu().numpy()
+        valid = np.zeros(len(st), bool)
+        for n in range(len(st)):
+            b = n // K
+            rp = packed_rows[int(lat.row_off[b]) + b:]
+            s = int(d[f"{tag}_states"][r][n])
+            # a row is in the packed lattice iff it has arcs or is reachable; compare only those
+            valid[n] = (rp[s + 1] - rp[s]) == em_rows[n].sum()
+        assert valid.sum() >= len(st) // 2
+        assert np.array_equal(nxt[valid], ref[valid])
+        for L, key in ((5, "mask_len5"), (21, "mask_len21")):
+            got = ops.emission_mask(lat, st, k=K, inp=lb, pad=PAD, bos=BOS, eos=EOS, has_to_end=L > maxlen).cpu().numpy()
+            assert np.array_equal(got[valid], d[f"{tag}_{key}"][r][valid])
+
+
+def test_iwae_and_wfst_fixture(dev, golden_dir):
+    d = load(golden_dir, "iwae")
+    B, K, T = d["samples"].shape
+    stripped = O.stripping_pad(d["samples"].reshape(B * K, T), PAD)
+    log_p = O.wfst_score(d["theta"], stripped, PAD).reshape(B, K)
+    lm, log_w = ops.iwae(torch.from_numpy(log_p).to(dev), torch.from_numpy(d["log_q"]).to(dev))
+    assert np.max(np.abs(log_w.cpu().numpy() - d["log_w"])) <= TOL
+    assert np.max(np.abs(lm.cpu().numpy() - d["log_marginal"])) <= TOL
+    # forced walk of the reference's samples: every one is an accepting path, score = sum theta[mark]
+    lat = LatticeBatch.from_dense(d["emission"], d["transition"], device=dev)
+    marks = np.concatenate([np.full((B, K, 1), BOS, np.int64), d["samples"]], axis=2)
+    tot, end = ops.score_paths(lat, torch.from_numpy(d["theta"]), torch.from_numpy(marks))
+    assert np.array_equal(end.cpu().numpy(), np.repeat(lat.sink[:, None], K, 1))
+    ref = log_p + d["theta"][BOS]
+    assert np.max(np.abs(tot.cpu().numpy() - ref)) <= TOL
+
+
+@pytest.mark.parametrize("tag", ["norm_eval", "norm_eval_temp", "norm_eval_short", "raw_eval"])
+def test_path_logprob_fixture(dev, golden_dir, tag):
+    """evaluate_seq_with_temp of the reference (scorers.py:1530-1614), eval mode."""
+    d = load(golden_dir, "evalseq")
+    maxlen, norm, smooth, training, temp = d[tag + "_cfg"]
+    got = ops.path_logprob(torch.from_numpy(d["scores"]).to(dev), torch.from_numpy(d["seqs"]).to(dev), pad=PAD, bos=BOS,
+                           eos=EOS, max_length=int(maxlen), temp=float(temp), normalize=bool(norm)).cpu().numpy()
+    ref = d[tag]
+    same_special = (np.isnan(ref) & np.isnan(got)) | (np.isinf(ref) & (ref == got))
+    fin = np.isfinite(ref)
+    assert np.all(same_special | fin)
+    assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) <= 2e-5
+
+
+# ----------------------------------------------------------------------------- oracle parity
+def _mixed_batch():
+    return [
+        synth.layered_lattice(3, n_states=30, avg_degree=3.0, vocab=64, width=4, span=2),
+        synth.layered_lattice(4, n_states=300, avg_degree=8.0, vocab=64, width=9, span=5),
+        synth.layered_lattice(5, n_states=90, avg_degree=5.0, vocab=64, width=1, span=6),
+        synth.edit_lattice([10, 11, 12, 13, 14], [20, 21, 22, 23], vocab=64, seed=2),
+        synth.layered_lattice(6, n_states=700, avg_degree=10.0, vocab=64, width=16, span=8),
+        synth._finish(2, 64, [0], [EOS], [1]),
+    ]
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(lanes_policy=1), dict(max_step_words=32)])
+def test_forward_backward_matches_oracle(dev, opts):
+    lats = _mixed_batch()
+    theta = synth.label_scores(7, 64)
+    lat = LatticeBatch.from_synth(lats, device=dev, **opts)
+    r = ops.forward_backward(lat, torch.from_numpy(theta), want_grad_theta=True)
+    la, lb, post = r.logalpha.cpu().numpy(), r.logbeta.cpu().numpy(), r.posterior.cpu().numpy()
+    gth = r.grad_theta.cpu().numpy()
+    for b, l in enumerate(lats):
+        o, _ = oracle_fb(l, theta)
+        r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
+        cmp_rows(la[r0:r0 + l.n_rows], o["logalpha"])
+        cmp_rows(lb[r0:r0 + l.n_rows], o["logbeta"])
+        assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL
+        assert abs(float(r.logz[b]) - o["logZ"]) <= TOL
+        assert np.max(np.abs(post[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
+        ref_g = np.bincount(l.label, weights=o["posterior"], minlength=64)
+        assert np.max(np.abs(gth[b] - ref_g)) <= 1e-4
+    # beta-only kernel agrees with the fused one bit for bit
+    rb = ops.backward(lat, torch.from_numpy(theta))
+    assert torch.equal(rb.logbeta, r.logbeta) and torch.equal(rb.logz64, r.logz64)
+
+
+def test_weighted_tables_and_arc_scores(dev):
+    """float emission tables (get_state_mask_pynini weighted=True, scorers.py:1011-1027)
+    and caller-supplied per-arc scores; per-lattice theta [B, V]."""
+    lats = [synth.layered_lattice(s, n_states=150 + 20 * s, avg_degree=6.0, vocab=48, width=7, span=3, weighted=True)
+            for s in range(4)]
+    em, tr = synth.collate_dense([l.dense(weighted=True) for l in lats])
+    lat = LatticeBatch.from_dense(em, tr, device=dev)
+    assert lat.weighted == 1
+    rng = np.random.default_rng(0)
+    theta = rng.normal(-2.0, 0.7, size=(len(lats), 48)).astype(np.float32)
+    arc_scores = rng.normal(0.0, 0.3, size=lat.total_arcs).astype(np.float32)
+    r = ops.forward_backward(lat, torch.from_numpy(theta), arc_scores=torch.from_numpy(arc_scores))
+    g = ops.gather_label_scores(lat, torch.from_numpy(theta), torch.from_numpy(arc_scores)).cpu().numpy()
+    for b, l in enumerate(lats):
+        a0 = int(lat.arc_off[b])
+        asc = arc_scores[a0:a0 + l.n_arcs]
+        o, sc = oracle_fb(l, theta[b], asc)
+        assert np.max(np.abs(g[a0:a0 + l.n_arcs] - sc)) <= 2e-6
+        r0 = int(lat.row_off[b])
+        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"])
+        cmp_rows(r.logalpha.cpu().numpy()[r0:r0 + l.n_rows], o["logalpha"])
+        assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL
+        assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
+
+
+def test_extreme_scores_do_not_overflow(dev):
+    """The reference's probability-domain beta overflows float32 once log Z > 88
+    (SURVEY.md section 6); the (mantissa, exponent) semiring must not."""
+    l = synth.layered_lattice(11, n_states=400, avg_degree=8.0, vocab=64, width=8, span=4)
+    for mean in (6.0, -40.0):
+        theta = synth.label_scores(3, 64, mean=mean, std=1.0)
+        lat = LatticeBatch.from_synth([l], device=dev)
+        r = ops.forward_backward(lat, torch.from_numpy(theta))
+        o, _ = oracle_fb(l, theta)
+        assert abs(o["logZ"]) > 200
+        assert abs(float(r.logz64[0]) - o["logZ"]) <= 1e-5 * max(1.0, abs(o["logZ"]) / 16)
+        assert np.max(np.abs(r.posterior.cpu().numpy() - o["posterior"])) <= 5e-6
+    # a forbidden label (-inf) removes its arcs
+    theta = synth.label_scores(3, 64)
+    theta[l.label[5]] = -np.inf
+    r = ops.forward_backward(LatticeBatch.from_synth([l], device=dev), torch.from_numpy(theta))
+    o, _ = oracle_fb(l, theta)
+    assert abs(float(r.logz64[0]) - o["logZ"]) <= TOL
+
+
+def test_huge_degree_and_deep_lattices(dev):
+    V = 256
+    src = [0] + [1] * 200 + list(range(2, 202)) + [202]
+    lab = [BOS] + list(range(3, 203)) + [5] * 200 + [EOS]
+    dst = [1] + list(range(2, 202)) + [202] * 200 + [203]
+    star = synth._finish(204, V, src, lab, dst)
+    deep = synth.layered_lattice(5, n_states=1500, avg_degree=10.0, vocab=V, width=1, span=8)
+    theta = synth.label_scores(2, V)
+    for opts in (dict(max_step_words=40), dict()):
+        lat = LatticeBatch.from_synth([star, deep], device=dev, **opts)
+        r = ops.forward_backward(lat, torch.from_numpy(theta))
+        for b, l in enumerate([star, deep]):
+            o, _ = oracle_fb(l, theta)
+            assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL
+            a0 = int(lat.arc_off[b])
+            assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
+
+
+def test_autograd_gives_posteriors(dev):
+    lats = _mixed_batch()[:5]
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    theta = torch.from_numpy(synth.label_scores(7, 64)).to(dev).requires_grad_(True)
+    arc_scores = torch.zeros(lat.total_arcs, device=dev, requires_grad=True)
+    z = ops.log_z(lat, theta, arc_scores)
+    wts = torch.arange(1, len(lats) + 1, device=dev, dtype=torch.float32)
+    (z * wts).sum().backward()
+    ref_theta = np.zeros(64)
+    for b, l in enumerate(lats):
+        o, _ = oracle_fb(l, theta.detach().cpu().numpy())
+        a0 = int(lat.arc_off[b])
+        assert np.max(np.abs(arc_scores.grad.cpu().numpy()[a0:a0 + l.n_arcs] - (b + 1) * o["posterior"])) <= 1e-5
+        ref_theta += (b + 1) * np.bincount(l.label, weights=o["posterior"], minlength=64)
+    assert np.max(np.abs(theta.grad.cpu().numpy() - ref_theta)) <= 1e-3
+
+
+def test_viterbi_bit_exact(dev):
+    lats = _mixed_batch()
+    theta = synth.label_scores(8, 64)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    r = ops.viterbi(lat, torch.from_numpy(theta), pad=PAD)
+    for b, l in enumerate(lats):
+        best, path, arcs = O.viterbi(l.n_rows, l.src, l.label, l.dst, theta[l.label], 4000)
+        n = int(r.lengths[b])
+        assert n == len(path)
+        assert np.float32(best) == r.best.cpu().numpy()[b]  # same float32 adds, same order
+        assert np.array_equal(r.paths.cpu().numpy()[b, :n], path)
+        assert np.array_equal(r.arcs.cpu().numpy()[b, :n] - int(lat.arc_off[b]), arcs)
+        assert np.all(r.paths.cpu().numpy()[b, n:] == PAD)
+
+
+def test_posterior_sampling(dev):
+    lats = _mixed_batch()[:5]
+    theta = synth.label_scores(9, 64)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    K, T = 512, int(lat.depth.max()) + 1
+    rng = np.random.default_rng(1)
+    u = rng.random((len(lats), K, T)).astype(np.float32)
+    s = ops.sample_paths(lat, torch.from_numpy(theta), K, max_len=T, uniforms=torch.from_numpy(u), pad=PAD)
+    paths, arcs, lens, logq = (x.cpu().numpy() for x in (s.paths, s.arcs, s.lengths, s.logq))
+    for b, l in enumerate(lats):
+        o, sc = oracle_fb(l, theta)
+        ref = O.sample_paths(l.n_rows, l.src, l.label, l.dst, sc, o["logbeta"], u[b].astype(np.float64), PAD)
+        safe = ref["margin"] > 1e-5  # walks whose uniforms stay clear of every CDF boundary
+        assert safe.mean() > 0.97
+        assert np.array_equal(paths[b][safe], ref["paths"][safe])
+        assert np.array_equal(lens[b][safe], ref["lengths"][safe])
+        assert np.array_equal((arcs[b] - np.where(arcs[b] >= 0, int(lat.arc_off[b]), 0))[safe], ref["arcs"][safe])
+        # every walk (safe or not) is an accepting path with log q = score - log Z
+        for k in range(0, K, 37):
+            a = arcs[b, k, :lens[b, k]] - int(lat.arc_off[b])
+            assert l.src[a[0]] == 0 and l.dst[a[-1]] == l.n_rows - 1 and np.all(l.dst[a[:-1]] == l.src[a[1:]])
+            assert abs(sc[a].sum() - o["logZ"] - logq[b, k]) <= 2e-5
+    # IWAE with the exact posterior as proposal has zero variance: every log w == log Z
+    tot, end = ops.score_paths(lat, torch.from_numpy(theta), s.paths)
+    lm, log_w = ops.iwae(tot, s.logq)
+    z = s.logz.cpu().numpy()
+    assert np.max(np.abs(log_w.cpu().numpy() - z[:, None])) <= 5e-5
+    assert np.max(np.abs(lm.cpu().numpy() - z)) <= 5e-5
+    # the Philox path is deterministic in the seed and follows the posterior
+    a = ops.sample_paths(lat, torch.from_numpy(theta), 2048, seed=11, pad=PAD)
+    b2 = ops.sample_paths(lat, torch.from_numpy(theta), 2048, seed=11, pad=PAD)
+    c = ops.sample_paths(lat, torch.from_numpy(theta), 2048, seed=12, pad=PAD)
+    assert torch.equal(a.paths, b2.paths) and not torch.equal(a.paths, c.paths)
+    for b, l in enumerate(lats[:2]):
+        o, _ = oracle_fb(l, theta)
+        ar = a.arcs.cpu().numpy()[b]
+        cnt = np.bincount(ar[ar >= 0] - int(lat.arc_off[b]), minlength=l.n_arcs) / 2048.0
+        assert np.max(np.abs(cnt - o["posterior"])) < 0.06
+
+
+def test_beta_logits_gather(dev):
+    lats = _mixed_batch()[:3]
+    K = 4
+    em, tr = synth.collate_dense([l.dense() for l in lats])
+    lat = LatticeBatch.from_dense(em, tr, device=dev)
+    theta = synth.label_scores(3, 64)
+    r = ops.backward(lat, torch.from_numpy(theta))
+    rng = np.random.default_rng(5)
+    # walkers sit on reachable states
+    states = np.array([rng.choice(np.unique(lats[n // K].src)) for n in range(len(lats) * K)], np.int64)
+    got = ops.beta_logits(lat, r.logbeta, torch.from_numpy(states), k=K).cpu().numpy()
+    beta = lat.rows_view(r.logbeta).cpu().numpy()
+    ref = O.beta_logits(O.expand_k(tr, K), np.repeat(beta, K, 0), states)
+    assert np.array_equal(got, ref)
+
+
+# ----------------------------------------------------------------------------- BASELINE size
+def test_baseline_batch_properties_and_oracle(dev):
+    """256 synthetic lattices of ~2k states / ~20k arcs (BASELINE.json configs[1])."""
+    B = 256
+    lats = synth.bench_batch(B)
+    theta = synth.label_scores(1, 256)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    assert 4.5e6 < lat.total_arcs < 5.6e6
+    r = ops.forward_backward(lat, torch.from_numpy(theta))
+    n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lats)
+    zref, pref = O.forward_backward_batch(n_rows, arc_off, src, label, dst, None, theta, n_threads=8)
+    assert np.max(np.abs(r.logz64.cpu().numpy() - zref)) <= TOL
+    assert np.max(np.abs(r.logz.cpu().numpy() - zref)) <= TOL
+    post = r.posterior.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(post - pref)) <= 2e-6
+    la = r.logalpha.cpu().numpy()
+    # size-independent identities: Z from alpha == Z from beta; unit flow out of the start and
+    # into the sink; flow conservation at every inner state
+    sink_rows = lat.row_off + lat.sink
+    assert np.max(np.abs(la[sink_rows] - r.logz.cpu().numpy())) <= TOL
+    lat_of = np.repeat(np.arange(B), np.diff(arc_off))
+    gsrc = src + lat.row_off[lat_of]
+    gdst = dst + lat.row_off[lat_of]
+    nl = src != dst
+    outflow = np.bincount(gsrc[nl], weights=post[nl], minlength=lat.total_rows)
+    inflow = np.bincount(gdst[nl], weights=post[nl], minlength=lat.total_rows)
+    assert np.max(np.abs(outflow[lat.row_off] - 1.0)) <= 2e-5
+    assert np.max(np.abs(inflow[sink_rows] - 1.0)) <= 2e-5
+    inner = np.ones(lat.total_rows, bool); inner[lat.row_off] = False; inner[sink_rows] = False
+    assert np.max(np.abs(inflow[inner] - outflow[inner])) <= 2e-5
+    # run-to-run determinism of everything but the LDS label histogram
+    r2 = ops.forward_backward(lat, torch.from_numpy(theta))
+    assert torch.equal(r.posterior, r2.posterior) and torch.equal(r.logz64, r2.logz64)

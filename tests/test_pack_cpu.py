@@ -1,0 +1,153 @@
+"""Host packer (nfst_amd/csrc/pack.cpp) and C-ABI surface -- CPU only."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from nfst_amd import _lib, synth
+from nfst_amd.lattice import LatticeBatch
+from tests.stream_check import replay
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nfst_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nfst_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in nfst_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+    assert _lib.lib.nfst_abi_version() == 1
+
+
+def test_ops_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nfst_amd import ops
+    lat = LatticeBatch.from_synth([synth.layered_lattice(1, n_states=20, avg_degree=3, vocab=32, width=3, span=2)])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.forward_backward(lat, torch.zeros(32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.path_logprob(torch.zeros(1, 2, 8), torch.zeros(1, 2, dtype=torch.long))
+
+
+def _cases():
+    return [
+        synth.layered_lattice(3, n_states=30, avg_degree=3.0, vocab=40, width=4, span=2),
+        synth.layered_lattice(4, n_states=200, avg_degree=8.0, vocab=64, width=9, span=5),
+        synth.layered_lattice(5, n_states=64, avg_degree=5.0, vocab=48, width=1, span=6),  # near-sequential
+        synth.edit_lattice([10, 11, 12, 13], [20, 21, 22], vocab=40, seed=2),
+        synth.layered_lattice(6, n_states=150, avg_degree=6.0, vocab=64, width=7, span=3, weighted=True),
+    ]
+
+
+@pytest.mark.parametrize("pad", [0, 7])
+def test_dense_pack_matches_oracle_arcs(pad):
+    lats = _cases()[:4]
+    em, tr = synth.collate_dense([l.dense() for l in [synth.layered_lattice(3, n_states=30, avg_degree=3.0, vocab=40, width=4, span=2),
+                                                      synth.edit_lattice([10, 11, 12, 13], [20, 21, 22], vocab=40, seed=2)]], pad=pad)
+    lat = LatticeBatch.from_dense(em, tr)
+    assert lat.uniform_rows and lat.n_rows[0] == em.shape[1]
+    for b in range(em.shape[0]):
+        src, label, dst, _ = O.dense_to_arcs(em[b], tr[b])
+        a0, n = int(lat.arc_off[b]), int(lat.n_arcs[b])
+        assert n == src.shape[0]
+        assert np.array_equal(lat.arc_src.numpy()[a0:a0 + n], src)
+        assert np.array_equal(lat.arc_label.numpy()[a0:a0 + n], label)
+        assert np.array_equal(lat.arc_dst.numpy()[a0:a0 + n], dst)
+        rp = lat.row_ptr.numpy()[int(lat.row_off[b]) + b: int(lat.row_off[b]) + b + int(lat.n_rows[b]) + 1]
+        assert rp[0] == a0 and rp[-1] == a0 + n and np.all(np.diff(rp) >= 0)
+        assert np.array_equal(np.diff(rp), np.bincount(src, minlength=int(lat.n_rows[b])))
+
+
+def test_dense_and_arc_front_ends_agree():
+    lats = [synth.layered_lattice(s, n_states=120, avg_degree=6.0, vocab=64, width=6, span=4) for s in (1, 2, 3)]
+    a = LatticeBatch.from_synth(lats)
+    em, tr = synth.collate_dense([l.dense() for l in lats])
+    d = LatticeBatch.from_dense(em, tr)
+    for k in ("arc_src", "arc_dst", "arc_label", "fwd_stream", "bwd_stream", "fwd_perm", "bwd_perm"):
+        assert torch.equal(getattr(a, k), getattr(d, k)), k
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(lanes_policy=1), dict(max_step_words=24), dict(max_step_words=64, lanes_policy=1)])
+def test_streams_replay_to_oracle_values(opts):
+    lats = _cases()
+    theta = synth.label_scores(9, 64)
+    for l in lats:
+        lat = LatticeBatch.from_synth([l], **opts)
+        extra = lat.arc_w.numpy() if l.weight is not None else None
+        sc = theta[l.label].astype(np.float64) + (l.weight.astype(np.float64) if l.weight is not None else 0.0)
+        r = O.forward_backward(l.n_rows, l.src, l.dst, sc)
+        beta = replay(lat, 0, "bwd", theta, extra)
+        alpha = replay(lat, 0, "fwd", theta, extra)
+        assert np.allclose(beta, r["logbeta"], atol=1e-9, equal_nan=True)
+        assert np.allclose(alpha, r["logalpha"], atol=1e-9, equal_nan=True)
+        assert lat.depth[0] >= 2 and lat.sink[0] == l.n_rows - 1
+
+
+def test_huge_degree_state_is_split_into_accumulate_steps():
+    # star: 0 -bos-> 1, 1 -> {2..201} (200 arcs), all -> 202 (in-degree 200), 202 -eos-> sink 203
+    V = 256
+    src = [0] + [1] * 200 + list(range(2, 202)) + [202]
+    lab = [synth.BOS] + list(range(3, 203)) + [5] * 200 + [synth.EOS]
+    dst = [1] + list(range(2, 202)) + [202] * 200 + [203]
+    l = synth._finish(204, V, src, lab, dst)
+    lat = LatticeBatch.from_synth([l], max_step_words=40)
+    theta = synth.label_scores(2, V)
+    r = O.forward_backward(l.n_rows, l.src, l.dst, theta[l.label].astype(np.float64))
+    assert np.allclose(replay(lat, 0, "bwd", theta), r["logbeta"], atol=1e-9)
+    assert np.allclose(replay(lat, 0, "fwd", theta), r["logalpha"], atol=1e-9)
+    s = lat.fwd_stream.numpy().view(np.uint32)
+    assert any((int(w) >> 20) & 1 for w in s[: int(lat.meta_host[0][_lib.META_FWD_WORDS])])  # accumulate flag used
+
+
+def test_pack_rejects_bad_lattices():
+    V = 8
+    def arcs(src, lab, dst, n):
+        return dict(n_rows=np.array([n], np.int32), arc_off=np.array([0, len(src)], np.int64), src=np.array(src, np.int32),
+                    label=np.array(lab, np.int32), dst=np.array(dst, np.int32), vocab=V)
+    with pytest.raises(_lib.NfstError) as e:  # 0 -> 1 -> 2 -> 1
+        LatticeBatch.from_arcs(**arcs([0, 1, 2, 2], [1, 3, 3, 4], [1, 2, 1, 3], 4))
+    assert e.value.code == -3 and e.value.lattice == 0
+    with pytest.raises(_lib.NfstError) as e:  # two states without out arcs
+        LatticeBatch.from_arcs(**arcs([0, 0], [3, 4], [1, 2], 3))
+    assert e.value.code == -4
+    with pytest.raises(_lib.NfstError) as e:  # same (state, label) twice
+        LatticeBatch.from_arcs(**arcs([0, 0, 1], [3, 3, 2], [1, 1, 2], 3))
+    assert e.value.code == -5
+    with pytest.raises(_lib.NfstError) as e:  # state index out of range
+        LatticeBatch.from_arcs(**arcs([0], [3], [5], 2))
+    assert e.value.code == -2
+    with pytest.raises(_lib.NfstError) as e:  # more rows than the LDS-resident engine takes
+        LatticeBatch.from_arcs(**arcs([0], [3], [1], 9000))
+    assert e.value.code == -6
+
+
+def test_trivial_and_padded_lattices():
+    V = 8
+    # a single arc 0 -eos-> sink, padded with junk rows that claim arcs everywhere (pad id 3)
+    l = synth._finish(2, V, [0], [synth.EOS], [1])
+    em, tr = l.dense()
+    em, tr = em[None], tr[None]
+    big = np.full((1, 6, V), 3, dtype=tr.dtype); big[0, :2] = tr[0]
+    bem = np.ones((1, 6, V), dtype=bool); bem[0, :2] = em[0]
+    lat = LatticeBatch.from_dense(bem, big)
+    assert lat.total_arcs == 2 and lat.total_dp_arcs == 1 and lat.sink[0] == 1 and lat.depth[0] == 1
+    assert lat.n_rows[0] == 6
+
+
+def test_synth_is_deterministic():
+    a = synth.layered_lattice(1234)
+    b = synth.layered_lattice(1234)
+    assert np.array_equal(a.src, b.src) and np.array_equal(a.label, b.label) and np.array_equal(a.dst, b.dst)
+    assert 1800 <= a.n_rows <= 2202 and 15000 < a.n_arcs < 26000
+    # the checksum pins the generator across machines / numpy builds
+    h = int((a.src.astype(np.int64) * 31 + a.label * 17 + a.dst).sum() % (2 ** 31))
+    assert h == int((b.src.astype(np.int64) * 31 + b.label * 17 + b.dst).sum() % (2 ** 31))
