@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- lattice-arcs/sec of the forward-backward (log-Z) hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of ``nfst_forward_backward`` (alpha sweep, beta sweep, exact
+log Z, arc posteriors; float32 arithmetic in an extended-exponent probability
+semiring) over one batch of synthetic lattices that is already resident in HBM:
+BASELINE.json configs[1], 256 lattices of ~2k states / ~20k arcs per GPU
+(``nfst_amd.synth.bench_batch``, seeds 1234+i).  With N > 1 every rank owns its
+own 256 lattices (weak scaling, no data-path collective) and the only exchange
+is the RCCL all-reduce of the scalar loss sum(log Z) at the end of each step.
+
+Rank 0 prints one JSON line: value = lattice arcs processed by all ranks per
+second; ``roofline`` = algorithmic HBM bytes (32 B/arc +
+24 B/state) per launch / average kernel duration from HIP events, against the
+8 TB/s HBM3E peak; ``cpu_baseline`` = the CPU oracle's float64 forward-backward
+(oracle/nfst_oracle.c, OpenMP over lattices) on the same batch on this box's
+host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(lats, theta, budget_s=12.0):
+    """The oracle (a port of the reference's path-sum semantics, float64) timed on
+    the host cores over the same lattices; repeated until ~budget_s of work."""
+    from oracle import oracle as O
+    from nfst_amd import synth
+
+    cores = os.cpu_count() or 1
+    n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lats)
+    dp = int((src != dst).sum())
+    O.forward_backward_batch(n_rows, arc_off, src, label, dst, w, theta, n_threads=cores)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.forward_backward_batch(n_rows, arc_off, src, label, dst, w, theta, n_threads=cores)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or reps >= 200:
+            break
+    out = {"value": dp * reps / dt, "unit": "lattice-arcs/s", "cores": cores, "kind": "port",
+           "sample": f"{len(lats)} lattices ({dp} arcs) x {reps} passes, float64 log-semiring forward-backward, "
+                     f"OpenMP over lattices, {dt:.1f} s"}
+    # the reference's own algorithm (compute_beta_parallel: dense [S,S] frontier loop, H=8) on one
+    # small lattice -- its cost grows ~S^3, a 2k-state lattice takes minutes
+    try:
+        small = synth.layered_lattice(1234, n_states=300, avg_degree=8.0, vocab=64, width=8, span=4)
+        _, tr = small.dense()
+        rng = np.random.default_rng(0)
+        H = 8
+        emb, Wx = rng.normal(size=(64, H)).astype(np.float32), (0.3 * rng.normal(size=(H, H))).astype(np.float32)
+        Wh, W, bias = np.zeros((H, H), np.float32), rng.normal(size=H).astype(np.float32), np.zeros(H, np.float32)
+        t0 = time.perf_counter()
+        O.beta_dense_frontier(tr, emb, Wx, Wh, W, bias)
+        dt = time.perf_counter() - t0
+        out["reference_dense_frontier"] = {"value": int((small.src != small.dst).sum()) / dt, "unit": "lattice-arcs/s",
+                                           "cores": 1, "sample": f"one lattice S=300, beta sweep only, {dt:.2f} s"}
+    except Exception as e:  # the extra line is informational
+        out["reference_dense_frontier"] = {"error": str(e)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--lattices-per-gpu", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--lanes-policy", type=int, default=0)
+    ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X (no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nfst_amd import ops, synth
+    from nfst_amd.lattice import LatticeBatch
+    from nfst_amd.distributed import all_reduce_loss
+
+    B = args.lattices_per_gpu
+    lats = synth.bench_batch(B, first_seed=1234 + rank * B, width=args.width)
+    theta_np = synth.label_scores(1, 256)
+    t0 = time.perf_counter()
+    lat = LatticeBatch.from_synth(lats, lanes_policy=args.lanes_policy)
+    pack_s = time.perf_counter() - t0
+    lat = lat.to(dev)
+    theta = torch.from_numpy(theta_np).to(dev)
+    arcs = int(lat.n_dp_arcs.sum())
+    alg_bytes = lat.algorithmic_bytes("forward_backward")
+
+    def step():
+        r = ops.forward_backward(lat, theta, want_alpha_beta=True, want_posterior=True)
+        loss = -r.logz64.sum()
+        if world > 1:
+            loss = all_reduce_loss(loss)
+        return r, loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        r = ops.forward_backward(lat, theta, want_alpha_beta=True, want_posterior=True)
+        ev[i][1].record()
+        loss = -r.logz64.sum()
+        if world > 1:
+            loss = all_reduce_loss(loss)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    total_arcs = arcs
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.tensor([arcs], dtype=torch.float64, device=dev)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        total_arcs = int(a.item())
+    if rank == 0:
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "lattice-arcs/sec forward-backward (log-Z)",
+            "value": total_arcs * args.steps / dt,
+            "unit": "lattice-arcs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {B} synthetic lattices per GPU, ~2k states / ~20k arcs "
+                                   f"(layer width {args.width}), alpha+beta+logZ+arc posteriors",
+                       "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
+                       "max_depth": int(lat.depth.max()), "loss": float(loss.item()), "host_pack_s": pack_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_forward_backward", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lats, theta_np, args.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

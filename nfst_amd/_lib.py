@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first, so that torch's bundled HIP runtime is the one the process uses
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnfst_hip.so")
 

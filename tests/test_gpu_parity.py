@@ -68,29 +68,16 @@ def test_state_advance_and_masks_bit_exact(dev, golden_dir, tag):
     d = load(golden_dir, "gather")
     K, maxlen = int(d["K"]), int(d["max_length"])
     lat = LatticeBatch.from_dense(d[f"{tag}_emission"], d[f"{tag}_transition"], device=dev)
-    n_rows = d["n_rows"]
     for r in range(d[f"{tag}_states"].shape[0]):
         st = torch.from_numpy(d[f"{tag}_states"][r]).to(dev)
         lb = torch.from_numpy(d[f"{tag}_labels"][r]).to(dev)
         nxt = ops.step(lat, st, lb, k=K).cpu().numpy()
-        # rows the reference tables hold but that cannot be reached from state 0
-        # (the machine's old final state, collate padding) are not part of the lattice
-        reach = np.array([np.isfinite(x) for x in np.zeros(len(st))])
+        # fixture walkers sit on rows of their own lattice (all reachable); collate padding rows are never visited
         ref = d[f"{tag}_next"][r]
-        em_rows = d[f"{tag}_emission"][np.arange(len(st)) // K, d[f"{tag}_states"][r]]
-        packed_rows = lat.row_ptr.cpu().numpy()
-        valid = np.zeros(len(st), bool)
-        for n in range(len(st)):
-            b = n // K
-            rp = packed_rows[int(lat.row_off[b]) + b:]
-            s = int(d[f"{tag}_states"][r][n])
-            # a row is in the packed lattice iff it has arcs or is reachable; compare only those
-            valid[n] = (rp[s + 1] - rp[s]) == em_rows[n].sum()
-        assert valid.sum() >= len(st) // 2
-        assert np.array_equal(nxt[valid], ref[valid])
+        assert np.array_equal(nxt, ref)
         for L, key in ((5, "mask_len5"), (21, "mask_len21")):
             got = ops.emission_mask(lat, st, k=K, inp=lb, pad=PAD, bos=BOS, eos=EOS, has_to_end=L > maxlen).cpu().numpy()
-            assert np.array_equal(got[valid], d[f"{tag}_{key}"][r][valid])
+            assert np.array_equal(got, d[f"{tag}_{key}"][r])
 
 
 def test_iwae_and_wfst_fixture(dev, golden_dir):
