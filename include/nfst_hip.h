@@ -71,6 +71,7 @@ extern "C" {
 /* limits of the LDS-resident kernels */
 #define NFST_MAX_ROWS 8192     /* states per lattice incl. sink (alpha+beta live in LDS) */
 #define NFST_MAX_VOCAB 32768   /* labels are packed in 16 bits of an arc record */
+#define NFST_MAX_STEP_WORDS 512 /* a step is at most one 2 KiB block of the 16 KiB LDS ring */
 
 /* per-lattice metadata: NFST_META_WORDS int32 each, see DESIGN.md */
 #define NFST_META_WORDS 16
@@ -107,6 +108,8 @@ typedef struct nfst_batch {
   int32_t max_rows;        /* max n_rows over the batch */
   int32_t max_steps;       /* max(fwd_steps, bwd_steps) over the batch */
   int32_t weighted;        /* arc_w holds the table's float weights */
+  int32_t max_step_words;  /* no step of a stream is longer (<= NFST_MAX_STEP_WORDS) */
+  int32_t sweep_waves;     /* waves per sweep direction the schedule was laid out for: 1, 2 or 4 */
   int32_t reserved0;
   int64_t total_rows;
   int64_t total_arcs;
@@ -136,9 +139,9 @@ typedef struct nfst_packed nfst_packed; /* opaque, owns host arrays */
 /* pack options; zero-initialise for defaults */
 typedef struct nfst_pack_opts {
   int32_t n_threads;       /* host threads over lattices (0 = hardware) */
-  int32_t max_step_words;  /* a step never exceeds this many stream words (0 = 2048) */
+  int32_t max_step_words;  /* a step never exceeds this many stream words (0 = 512 = max) */
   int32_t lanes_policy;    /* 0 = latency (fill the waves), 1 = throughput (few lanes/state) */
-  int32_t sweep_waves;     /* waves per sweep direction assumed by policy 0 (0 = 4) */
+  int32_t sweep_waves;     /* waves per sweep direction: 1, 2 or 4 (0 = choose from the level widths) */
 } nfst_pack_opts;
 
 /*

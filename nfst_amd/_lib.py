@@ -35,7 +35,7 @@ class NfstError(RuntimeError):
 class Batch(C.Structure):
     _fields_ = [
         ("n_lattices", C.c_int32), ("vocab", C.c_int32), ("max_rows", C.c_int32), ("max_steps", C.c_int32),
-        ("weighted", C.c_int32), ("reserved0", C.c_int32),
+        ("weighted", C.c_int32), ("max_step_words", C.c_int32), ("sweep_waves", C.c_int32), ("reserved0", C.c_int32),
         ("total_rows", C.c_int64), ("total_arcs", C.c_int64), ("total_dp_arcs", C.c_int64),
         ("fwd_words", C.c_int64), ("bwd_words", C.c_int64),
         ("meta", C.c_void_p), ("row_ptr", C.c_void_p), ("arc_src", C.c_void_p), ("arc_dst", C.c_void_p),

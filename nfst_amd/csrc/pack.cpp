@@ -22,7 +22,7 @@ namespace {
 
 struct Opts {
   int n_threads = 0;
-  int max_step_words = 2048;
+  int max_step_words = NFST_MAX_STEP_WORDS;
   int lanes_policy = 0;
   int sweep_waves = 4;
 };
@@ -40,15 +40,31 @@ struct Lat {
   int err = NFST_OK;
 };
 
+// Lanes per state (2^kl) for a step of n_states states whose largest degree is
+// maxdeg, run by W waves: minimise the instructions on one wave's critical path,
+//   tiles(kl) * (iters(kl) * c_iter + kl * c_reduce + c_fixed),
+// tiles = ceil(n_states * 2^kl / (64 W)), iters = ceil(maxdeg / 2^kl).
+// lanes_policy 1 ("throughput") instead keeps lanes busy: the smallest kl with
+// iters <= 4.
 int choose_klog(int n_states, int maxdeg, const Opts &o) {
   auto iters = [&](int kl) { return (maxdeg + (1 << kl) - 1) >> kl; };
-  int kl = 0;
-  while (kl < 6 && iters(kl) > 4) ++kl;
-  if (o.lanes_policy == 0) {
-    // latency: spend idle lanes of the sweep's waves to shorten the per-lane loop
-    while (kl < 6 && iters(kl) > 1 && ((int64_t)n_states << (kl + 1)) <= 64 * (int64_t)o.sweep_waves) ++kl;
+  if (o.lanes_policy == 1) {
+    int kl = 0;
+    while (kl < 6 && iters(kl) > 4) ++kl;
+    return kl;
   }
-  return kl;
+  const int64_t lanes = 64 * (int64_t)o.sweep_waves;
+  int best = 0;
+  int64_t best_cost = -1;
+  for (int kl = 0; kl <= 6; ++kl) {
+    const int64_t tiles = (((int64_t)n_states << kl) + lanes - 1) / lanes;
+    const int it = iters(kl);
+    // the first two arcs of a lane share one rescale; later ones use the online rule
+    const int64_t per_tile = 12 * std::min(it, 2) + 16 * std::max(it - 2, 0) + 3 * kl + (kl > 4 ? 12 * (kl - 4) : 0) + 24;
+    const int64_t cost = tiles * per_tile;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kl; }
+  }
+  return best;
 }
 
 // Emits the steps of one level.  states are sorted by degree (desc).  arcs_of(s)
@@ -206,9 +222,9 @@ Opts read_opts(const nfst_pack_opts *o) {
   Opts r;
   if (o) {
     r.n_threads = o->n_threads;
-    if (o->max_step_words > 0) r.max_step_words = o->max_step_words;
+    if (o->max_step_words > 0) r.max_step_words = std::min<int>(o->max_step_words, NFST_MAX_STEP_WORDS);
     r.lanes_policy = o->lanes_policy;
-    if (o->sweep_waves > 0) r.sweep_waves = o->sweep_waves;
+    if (o->sweep_waves == 1 || o->sweep_waves == 2 || o->sweep_waves == 4) r.sweep_waves = o->sweep_waves;
   }
   return r;
 }
@@ -244,18 +260,19 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
     m[NFST_META_DP_OFF] = (int32_t)dp; m[NFST_META_N_DP] = L.n_dp;
     m[NFST_META_FWD_WORDS] = (int32_t)L.fwd.size(); m[NFST_META_BWD_WORDS] = (int32_t)L.bwd.size();
     rows += L.n_rows; arcs += (int64_t)L.src.size(); dp += L.n_dp;
-    fw += (int64_t)L.fwd.size(); bw += (int64_t)L.bwd.size();
+    // every lattice's stream starts on a 256-byte boundary (LDS-DMA chunks are 16 B per lane)
+    fw += ((int64_t)L.fwd.size() + 63) / 64 * 64; bw += ((int64_t)L.bwd.size() + 63) / 64 * 64;
     max_rows = std::max(max_rows, L.n_rows);
     max_steps = std::max(max_steps, std::max(L.fwd_steps, L.bwd_steps));
     if (arcs > 0x7fffff00ll || fw > 0x7fffff00ll || bw > 0x7fffff00ll || rows > 0x7fffff00ll) {
       delete p; if (err_lattice) *err_lattice = b; return NFST_ERR_LIMIT;
     }
   }
-  // 4 words of slack at the end of each stream so that a kernel may read a
-  // (masked) word past the last step without leaving the allocation
+  // one LDS-DMA chunk (256 words) + a header of slack at the end of each stream: the
+  // last chunk of the last lattice is read whole
   p->row_ptr.resize(rows + B); p->arc_src.resize(arcs); p->arc_dst.resize(arcs); p->arc_label.resize(arcs);
   if (weighted) p->arc_w.resize(arcs);
-  p->fwd.assign(fw + 4, 0); p->bwd.assign(bw + 4, 0); p->fwd_perm.resize(dp); p->bwd_perm.resize(dp);
+  p->fwd.assign(fw + 512, 0); p->bwd.assign(bw + 512, 0); p->fwd_perm.resize(dp); p->bwd_perm.resize(dp);
   parallel_for(B, o.n_threads, [&](int b) {
     Lat &L = lats[b];
     const int32_t *m = &p->meta[(size_t)b * NFST_META_WORDS];
@@ -278,7 +295,9 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
   nfst_batch &v = p->view;
   v.n_lattices = B; v.vocab = vocab; v.max_rows = max_rows; v.max_steps = max_steps;
   v.weighted = weighted ? 1 : 0; v.total_rows = rows; v.total_arcs = arcs; v.total_dp_arcs = dp;
-  v.fwd_words = fw + 4; v.bwd_words = bw + 4;
+  v.fwd_words = fw + 512; v.bwd_words = bw + 512;
+  v.max_step_words = o.max_step_words;
+  v.sweep_waves = o.sweep_waves;
   v.meta = p->meta.data(); v.row_ptr = p->row_ptr.data(); v.arc_src = p->arc_src.data();
   v.arc_dst = p->arc_dst.data(); v.arc_label = p->arc_label.data();
   v.arc_w = weighted ? p->arc_w.data() : nullptr;

@@ -68,7 +68,7 @@ class LatticeBatch:
                 "bwd_perm": _view(v.bwd_perm, v.total_dp_arcs, C.c_int32, np.int32),
             }
             header = {k: int(getattr(v, k)) for k in ("n_lattices", "vocab", "max_rows", "max_steps", "weighted",
-                                                      "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
+                                                      "max_step_words", "sweep_waves", "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
                                                       "bwd_words")}
         finally:
             lib.nfst_packed_free(handle)

@@ -14,10 +14,13 @@
 
 #include "nfst_hip.h"
 
+__device__ unsigned long long g_dbg[8192];
+extern "C" int nfst_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long)*8192); }
 namespace {
+#define STAMP(slot) do { if (dbg_on && t >= 20 && t < 52) { unsigned long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory"); if (lane == 0) g_dbg[dbg_base + (t-20)*8 + (slot)] = c_; } } while(0)
 
 constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
-constexpr int kViterbiWaves = 4;        // waves of the Viterbi kernel
+constexpr int kSweepWaves = 4;          // waves per sweep direction
 constexpr float kNegInf = -__builtin_huge_valf();
 
 struct ME {
@@ -100,84 +103,61 @@ struct Extra {
 };
 
 // ---------------------------------------------------------------- LDS ring (LDS-DMA)
-// A sweep consumes its stream strictly front to back and the stream does not
-// depend on the DP values, so it is prefetched far ahead: the sweep's W waves copy
-// 1-KiB chunks straight into a 16 KiB LDS ring with global_load_lds_dwordx4 (no
-// VGPR staging).  The ring is 8 blocks of 512 words (2 chunks each); chunk c is
-// issued by wave c % W and lives in slot c % 16.  A step is at most
-// NFST_MAX_STEP_WORDS = 512 words, so while the read offset is in block b a step
-// (plus the next step's 2-word header) touches blocks b .. b+2 only.  Protocol, run
-// by every wave when the offset enters block b ("crossing", at the top of a step,
-// i.e. after the barrier that ended the previous step):
-//   1. blocks < b are dead: issue the chunks this wave owns of block b+7 into them;
-//   2. counted wait: all of this wave's chunks of blocks <= b+3 have landed
-//      (blocks b+4 .. b+7 may stay in flight -- the constant vmcnt below);
-//   3. the barrier that ends this step publishes block b+3, one crossing before
-//      any wave can read it.
-// The prologue issues blocks 0..7 and waits for blocks 0..3 with the same constant.
+// A sweep consumes its stream strictly front to back, and the stream does not
+// depend on the DP values, so it is prefetched arbitrarily far ahead: each of the
+// sweep's 4 waves copies every 4th 1-KiB chunk straight into a 16 KiB LDS ring
+// with global_load_lds_dwordx4 (no VGPR staging).  Chunk c lives in slot c % 16.
+// Invariants (one step is at most NFST_MAX_STEP_WORDS = 1024 words):
+//   * before the barrier that ends step t-1 every wave has waited (counted vmcnt)
+//     for its chunks below word off_t + 1026: step t and the header of step t+1
+//     are then visible to all waves;
+//   * a slot is refilled only after a barrier that follows the last step reading it.
 constexpr int kRingWords = 4096;
 constexpr int kRingMask = kRingWords - 1;
 constexpr int kChunkWords = 256;
-constexpr int kBlockShift = 9;  // 512-word blocks
+constexpr int kSlots = kRingWords / kChunkWords;
+constexpr int kLookahead = NFST_MAX_STEP_WORDS + 2;
 
-template <int W>
 struct Ring {
-  uint32_t *lds;      // ring base in LDS
-  const uint32_t *g;  // this lattice's stream (256-byte aligned)
+  uint32_t *lds;        // ring base in LDS
+  const uint32_t *g;    // this lattice's stream (256-byte aligned)
   int total_chunks;
-  int blk;            // block holding the current read offset
-  int w;              // this wave's index within the sweep
+  int next_c;           // next chunk this wave issues: w, w+4, ...
+  int issued;           // chunks issued by this wave
+  int w;
 };
 
-template <int W>
-__device__ __forceinline__ void ring_issue_block(const Ring<W> &r, int block, int lane) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int c = 2 * block + q;
-    if ((c % W) != r.w) continue;
-    uint32_t *dst = r.lds + (c & 15) * kChunkWords;
-    if (c < r.total_chunks) {
-      const uint32_t *src = r.g + (size_t)c * kChunkWords + lane * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    } else {
-      // past the end of the stream: a 4-byte-per-lane placeholder load into the (dead)
-      // slot keeps the wave's vmcnt sequence identical, so the constant waits stay exact
-      const uint32_t *src = r.g + lane;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-    }
+__device__ __forceinline__ void ring_init(Ring &r, uint32_t *lds, const uint32_t *g, int words, int w) {
+  r.lds = lds; r.g = g; r.total_chunks = (words + kChunkWords - 1) / kChunkWords;
+  r.next_c = w; r.issued = 0; r.w = w;
+}
+
+// issue every chunk whose slot no longer holds words >= off (the first word still needed)
+__device__ __forceinline__ void ring_refill(Ring &r, int off, int lane) {
+  while (r.next_c < r.total_chunks && (r.next_c - kSlots + 1) * kChunkWords <= off) {
+    const uint32_t *src = r.g + (size_t)r.next_c * kChunkWords + lane * 4;
+    uint32_t *dst = r.lds + (r.next_c & (kSlots - 1)) * kChunkWords;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    r.next_c += kSweepWaves;
+    r.issued += 1;
   }
 }
 
-template <int W>
-__device__ __forceinline__ void ring_wait() {
-  // chunks a wave may leave in flight: its share of 4 blocks (8 chunks)
-  if (W == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (W == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-}
-
-template <int W>
-__device__ __forceinline__ void ring_start(Ring<W> &r, uint32_t *lds, const uint32_t *g, int words, int w,
-                                           int lane) {
-  r.lds = lds; r.g = g; r.total_chunks = (words + kChunkWords - 1) / kChunkWords; r.blk = 0; r.w = w;
-  for (int b = 0; b < 8; ++b) ring_issue_block(r, b, lane);
-  ring_wait<W>();
-}
-
-template <int W>
-__device__ __forceinline__ void ring_advance(Ring<W> &r, int off, int lane) {
-  const int nb = off >> kBlockShift;
-  if (nb != r.blk) {  // a step is at most one block long: nb == blk + 1
-    r.blk = nb;
-    ring_issue_block(r, nb + 7, lane);
-    ring_wait<W>();
-  }
+// wait until this wave's chunks covering words < need have landed
+__device__ __forceinline__ void ring_wait(const Ring &r, int need) {
+  int need_c = (need - 1) >> 8;
+  if (need_c > r.total_chunks - 1) need_c = r.total_chunks - 1;
+  const int n_need = need_c >= r.w ? ((need_c - r.w) >> 2) + 1 : 0;
+  const int allow = r.issued - n_need;  // loads that may stay in flight
+  if (allow <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (allow == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 }
 
 // workgroup barrier that does not drain the LDS-DMA queue (a __syncthreads() would
-// wait vmcnt(0)): this wave's LDS writes are complete, then s_barrier.
+// wait vmcnt(0)): LDS writes of this wave are complete, then s_barrier.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -187,150 +167,124 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
 
-// All-reduce of an (M, E) partial sum over groups of 2^KL neighbouring lanes:
-// max of the exponents, one rescale, then the sum.  Quad permutes and half-row /
-// row mirrors are DPP modifiers (no LDS traffic); 32- and 64-lane groups finish with
-// shuffles.  Every lane of a group ends with bitwise the same (M, E).
-template <int KL>
-__device__ __forceinline__ void group_reduce(float &M, int &E) {
-  int Em = E;
-  if (KL >= 1) Em = max(Em, dpp_i<0xB1>(Em));   // quad_perm [1,0,3,2]
-  if (KL >= 2) Em = max(Em, dpp_i<0x4E>(Em));   // quad_perm [2,3,0,1]
-  if (KL >= 3) Em = max(Em, dpp_i<0x141>(Em));  // row_half_mirror
-  if (KL >= 4) Em = max(Em, dpp_i<0x140>(Em));  // row_mirror
-  if (KL >= 5) Em = max(Em, __shfl_xor(Em, 16));
-  if (KL >= 6) Em = max(Em, __shfl_xor(Em, 32));
-  if (KL >= 1) {
-    M = ldexpf(M, E - Em);
-    E = Em;
+// (M, E) += partner's (M, E); PARTNER is a DPP control or a shuffle distance
+#define NFST_COMBINE_DPP(CTRL)                                            \
+  {                                                                       \
+    const float Mo = __int_as_float(dpp_i<CTRL>(__float_as_int(M)));      \
+    const int Eo = dpp_i<CTRL>(E);                                        \
+    const int En = max(E, Eo);                                            \
+    M = ldexpf(M, E - En) + ldexpf(Mo, Eo - En);                          \
+    E = En;                                                               \
   }
-  if (KL >= 1) M += dpp_f<0xB1>(M);
-  if (KL >= 2) M += dpp_f<0x4E>(M);
-  if (KL >= 3) M += dpp_f<0x141>(M);
-  if (KL >= 4) M += dpp_f<0x140>(M);
-  if (KL >= 5) M += __shfl_xor(M, 16);
-  if (KL >= 6) M += __shfl_xor(M, 32);
-}
-
-struct StepCtx {
-  const uint32_t *ring;
-  float2 *val;
-  const float2 *th;
-  Extra ex;
-  const int32_t *perm;  // + arc_base already applied
-  int st, rec, ns;
-  bool accum, has_extra;
-};
-
-__device__ __forceinline__ void arc_term(const StepCtx &c, int a, float &mt, int &et) {
-  const uint32_t rc = c.ring[(c.rec + a) & kRingMask];
-  const float2 tw = c.th[rc >> 16];
-  const float2 v = c.val[rc & 0xffffu];
-  float mw = tw.x;
-  int ew = __float_as_int(tw.y);
-  if (c.has_extra) {
-    ME x = exp_split(c.ex.at(c.perm[a]));
-    mw *= x.m;
-    ew += x.e;
+#define NFST_COMBINE_XOR(D)                                               \
+  {                                                                       \
+    const float Mo = __shfl_xor(M, D);                                    \
+    const int Eo = __shfl_xor(E, D);                                      \
+    const int En = max(E, Eo);                                            \
+    M = ldexpf(M, E - En) + ldexpf(Mo, Eo - En);                          \
+    E = En;                                                               \
   }
-  mt = mw * v.x;
-  et = ew + __float_as_int(v.y);
+
+// all-reduce of (M, E) over groups of 2^kl neighbouring lanes: quad permutes, then
+// half-row / row mirrors (DPP, no LDS traffic), then cross-row shuffles
+__device__ __forceinline__ void group_reduce(float &M, int &E, int kl) {
+  if (kl >= 1) NFST_COMBINE_DPP(0xB1)   // quad_perm [1,0,3,2]
+  if (kl >= 2) NFST_COMBINE_DPP(0x4E)   // quad_perm [2,3,0,1]
+  if (kl >= 3) NFST_COMBINE_DPP(0x141)  // row_half_mirror
+  if (kl >= 4) NFST_COMBINE_DPP(0x140)  // row_mirror
+  if (kl >= 5) NFST_COMBINE_XOR(16)
+  if (kl >= 6) NFST_COMBINE_XOR(32)
 }
 
-// The tiles of one step owned by wave w of W: 2^KL lanes per state, 64 >> KL states
-// per tile; the first two arcs of a lane are summed with one shared exponent, the
-// rest (rare: the packer keeps lanes at <= 2 arcs when it can) by the online rule.
-template <int KL, int W>
-__device__ __forceinline__ void step_tiles(const StepCtx &c, int w, int lane) {
-  constexpr int k = 1 << KL;
-  constexpr int spw = 64 >> KL;
-  for (int base = w * spw; base < c.ns; base += W * spw) {
-    const int i = base + (lane >> KL);
-    const int r = lane & (k - 1);
-    float M = 0.0f;
-    int E = kEZero;
-    uint32_t sid = 0;
-    if (i < c.ns) {
-      const uint32_t w0 = c.ring[(c.st + i) & kRingMask], w1 = c.ring[(c.st + i + 1) & kRingMask];
-      sid = w0 & 0xffffu;
-      const int a0 = (int)(w0 >> 16) + r, a1 = (int)(w1 >> 16);
-      float m0 = 0.0f, m1 = 0.0f;
-      int e0 = kEZero, e1 = kEZero;
-      if (a0 < a1) arc_term(c, a0, m0, e0);
-      if (a0 + k < a1) arc_term(c, a0 + k, m1, e1);
-      E = max(e0, e1);
-      M = ldexpf(m0, e0 - E) + ldexpf(m1, e1 - E);
-      for (int a = a0 + 2 * k; a < a1; a += k) {
-        float mt;
-        int et;
-        arc_term(c, a, mt, et);
-        me_acc(M, E, mt, et);
-      }
-    }
-    group_reduce<KL>(M, E);
-    if (i < c.ns && r == 0) {
-      if (c.accum) {
-        const float2 old = c.val[sid];
-        me_acc(M, E, old.x, __float_as_int(old.y));
-      }
-      c.val[sid] = me_pack(M, E);
-    }
-  }
-}
-
-// One sum-product sweep over one direction's stream, run by W waves (index w) of the
-// workgroup.  With W > 1 the waves meet at one barrier per step and every wave of the
-// workgroup must call lds_barrier() exactly n_barriers + 1 times; with W == 1 a sweep
-// is a single wave, its LDS accesses are ordered, and there is no barrier at all.
-template <int W>
-__device__ __forceinline__ void ring_sweep(const uint32_t *g, int words, uint32_t *ring_lds, int my_steps,
-                                           int n_barriers, float2 *val, const float2 *th, const Extra ex,
+// One sum-product sweep over one direction's stream, run by kSweepWaves waves
+// (index w) of the workgroup; every wave of the workgroup calls lds_barrier()
+// n_barriers times in total.
+__device__ __forceinline__ void ring_sweep(Ring &rg, int my_steps, int n_barriers, float2 *val,
+                                           const float2 *th, const Extra ex,
                                            const int32_t *__restrict__ perm, int w, int lane) {
-  Ring<W> rg;
-  ring_start(rg, ring_lds, g, words, w, lane);
-  if (W > 1) lds_barrier();
-  StepCtx c;
-  c.ring = ring_lds; c.val = val; c.th = th; c.ex = ex; c.has_extra = ex.any();
+  const uint32_t *ring = rg.lds;
+  const bool has_extra = ex.any();
+  const bool dbg_on = (blockIdx.x == 7);
+  const int dbg_base = (int)(threadIdx.x >> 6) * 512;
+  ring_refill(rg, 0, lane);
+  ring_wait(rg, kLookahead);
+  lds_barrier();
   int off = 0, arc_base = 0;
   uint32_t h0 = 0, na_u = 0;
   if (my_steps > 0) {
-    h0 = __builtin_amdgcn_readfirstlane(ring_lds[0]);
-    na_u = __builtin_amdgcn_readfirstlane(ring_lds[1]);
+    h0 = __builtin_amdgcn_readfirstlane(ring[0]);
+    na_u = __builtin_amdgcn_readfirstlane(ring[1]);
   }
   for (int t = 0; t < n_barriers; ++t) {
     if (t < my_steps) {
+      STAMP(0);
       const int na = (int)na_u;
+      const int ns = (int)(h0 & 0xffffu);
       const int kl = (int)((h0 >> 16) & 0xfu);
-      c.ns = (int)(h0 & 0xffffu);
-      c.accum = ((h0 >> 20) & 1u) != 0;
-      c.st = off + 2;
-      c.rec = c.st + c.ns + 1;
-      c.perm = perm + arc_base;
-      const int next_off = c.rec + na;
-      ring_advance(rg, off, lane);
-      // header of the next step: static data that has already landed
-      const uint32_t nh0 = ring_lds[next_off & kRingMask];
-      const uint32_t nna = ring_lds[(next_off + 1) & kRingMask];
-      switch (kl) {
-        case 0: step_tiles<0, W>(c, w, lane); break;
-        case 1: step_tiles<1, W>(c, w, lane); break;
-        case 2: step_tiles<2, W>(c, w, lane); break;
-        case 3: step_tiles<3, W>(c, w, lane); break;
-        case 4: step_tiles<4, W>(c, w, lane); break;
-        case 5: step_tiles<5, W>(c, w, lane); break;
-        default: step_tiles<6, W>(c, w, lane); break;
+      const bool accum = ((h0 >> 20) & 1u) != 0;
+      const int st = off + 2;
+      const int rec = st + ns + 1;
+      const int next_off = rec + na;
+      ring_refill(rg, off, lane);
+      // header of the next step (static data, already landed)
+      uint32_t nh0 = 0, nna = 0;
+      if (t + 1 < my_steps) {
+        nh0 = ring[next_off & kRingMask];
+        nna = ring[(next_off + 1) & kRingMask];
       }
+      STAMP(1);
+      const int spw = 64 >> kl;
+      const int k = 1 << kl;
+      for (int base = w * spw; base < ns; base += kSweepWaves * spw) {
+        const int i = base + (lane >> kl);
+        const int r = lane & (k - 1);
+        float M = 0.0f;
+        int E = kEZero;
+        uint32_t sid = 0;
+        if (i < ns) {
+          const uint32_t w0 = ring[(st + i) & kRingMask], w1 = ring[(st + i + 1) & kRingMask];
+          sid = w0 & 0xffffu;
+          const int a0 = (int)(w0 >> 16), a1 = (int)(w1 >> 16);
+          for (int a = a0 + r; a < a1; a += k) {
+            const uint32_t rc = ring[(rec + a) & kRingMask];
+            const float2 tw = th[rc >> 16];
+            const float2 v = val[rc & 0xffffu];
+            float mw = tw.x;
+            int ew = __float_as_int(tw.y);
+            if (has_extra) {
+              ME x = exp_split(ex.at(perm[arc_base + a]));
+              mw *= x.m;
+              ew += x.e;
+            }
+            me_acc(M, E, mw * v.x, ew + __float_as_int(v.y));
+          }
+        }
+        STAMP(2);
+        group_reduce(M, E, kl);
+        STAMP(3);
+        if (i < ns && r == 0) {
+          if (accum) {
+            const float2 old = val[sid];
+            const int Eo = __float_as_int(old.y);
+            const int En = max(E, Eo);
+            M = ldexpf(M, E - En) + ldexpf(old.x, Eo - En);
+            E = En;
+          }
+          val[sid] = me_pack(M, E);
+        }
+      }
+      STAMP(4);
       off = next_off;
       arc_base += na;
       h0 = __builtin_amdgcn_readfirstlane(nh0);
       na_u = __builtin_amdgcn_readfirstlane(nna);
+      // step t+1 and the header of step t+2 must be visible after the barrier
+      if (t + 1 < my_steps) ring_wait(rg, off + kLookahead);
+      STAMP(5);
     }
-    if (W > 1) lds_barrier();
+    lds_barrier();
+    STAMP(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight
 }
@@ -345,72 +299,48 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
 }
 
 // ------------------------------------------------------------------ backward only
-// W waves sweep the by-source stream from the sink (block = max(W, 2) * 64 threads...
-// exactly W * 64 threads).
-template <int W>
-__global__ __launch_bounds__(W * 64) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
-                                                     double *logz64, float *logz32, float2 *beta_me) {
+// 256 threads: 4 waves sweep the by-source stream from the sink.
+__global__ __launch_bounds__(256) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
+                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = W * 64;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Meta m = load_meta(lat.meta, b);
   const int rows2 = (lat.max_rows + 1) & ~1;
   float2 *beta = lds;
   float2 *th = lds + rows2;
   uint32_t *ring_lds = (uint32_t *)(th + ((lat.vocab + 1) & ~1));
-  for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
-  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
+  for (int i = tid; i < m.n_rows; i += 256) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, 256);
   __syncthreads();
   if (tid == 0) beta[m.sink] = make_float2(0.5f, __int_as_float(1));
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, m.bwd_steps, beta, th, ex,
-                lat.bwd_perm + m.dp_off, w, lane);
-  __syncthreads();
+  const int w = __builtin_amdgcn_readfirstlane(wave);
+  Ring rg;
+  ring_init(rg, ring_lds, lat.bwd_stream + m.bwd_off, m.bwd_words, w);
+  ring_sweep(rg, m.bwd_steps, m.bwd_steps, beta, th, ex, lat.bwd_perm + m.dp_off, w, lane);
   if (tid == 0) {
     const double z = me_log64(beta[0]);
     if (logz64) logz64[b] = z;
     if (logz32) logz32[b] = (float)z;
   }
-  for (int i = tid; i < m.n_rows; i += NT) {
+  for (int i = tid; i < m.n_rows; i += 256) {
     if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
     if (beta_me) beta_me[m.row_off + i] = beta[i];
   }
 }
 
 // ------------------------------------------------------------------ forward-backward
-// Waves [0, W) run the beta sweep and waves [W, 2W) the alpha sweep, concurrently;
-// then every wave of the block streams the canonical arcs once for the posteriors.
-// W = 1: 256-thread block, the two sweeps are single waves that never synchronise
-// (the other two waves wait at the barrier before the posterior pass).
-template <int W>
-struct FbGeom {
-  static constexpr int kThreads = (2 * W * 64 < 256) ? 256 : 2 * W * 64;
-};
-
-__device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv, const float2 tw, float rz,
-                                               int ez, bool has_extra, const Extra &ex, int a) {
-  float mw = tw.x;
-  int ew = __float_as_int(tw.y);
-  if (has_extra) {
-    ME x = exp_split(ex.at(a));
-    mw *= x.m;
-    ew += x.e;
-  }
-  const float mm = (av.x * mw) * (bv.x * rz);
-  const int ee = __float_as_int(av.y) + ew + __float_as_int(bv.y) - ez;
-  return ldexpf(mm, max(ee, -300));
-}
-
-template <int W>
-__global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
-    nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
-    double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
-    float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
+// 512 threads: waves 0-3 run the beta sweep, waves 4-7 the alpha sweep, level by
+// level and concurrently; then all waves stream the canonical arcs once more for
+// the posteriors.
+__global__ __launch_bounds__(512) void k_forward_backward(nfst_batch lat, nfst_scores sc,
+                                                          float *logalpha, float *logbeta,
+                                                          double *logz64, float *logz32,
+                                                          float *posterior, float *grad_theta,
+                                                          float2 *beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = FbGeom<W>::kThreads;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Meta m = load_meta(lat.meta, b);
   const int rows2 = (lat.max_rows + 1) & ~1;
   const int v4 = (lat.vocab + 3) & ~3;
@@ -419,12 +349,12 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
   float2 *th = lds + 2 * rows2;
   float *gth = (float *)(th + v4);             // [V] label histogram (only if grad_theta)
   uint32_t *ring_lds = (uint32_t *)(gth + v4);  // two 16 KiB rings: beta stream, alpha stream
-  for (int i = tid; i < m.n_rows; i += NT) {
+  for (int i = tid; i < m.n_rows; i += 512) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   }
-  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
-  if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, 512);
+  if (grad_theta) for (int l = tid; l < lat.vocab; l += 512) gth[l] = 0.0f;
   __syncthreads();
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
@@ -432,14 +362,17 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
   }
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const bool fwd = wv >= kSweepWaves;
+  const int w = fwd ? wv - kSweepWaves : wv;
   const int all_steps = max(m.fwd_steps, m.bwd_steps);
-  if (wv < W) {
-    ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, all_steps, beta, th, ex,
-                  lat.bwd_perm + m.dp_off, wv, lane);
-  } else if (wv < 2 * W) {
-    ring_sweep<W>(lat.fwd_stream + m.fwd_off, m.fwd_words, ring_lds + kRingWords, m.fwd_steps, all_steps,
-                  alpha, th, ex, lat.fwd_perm + m.dp_off, wv - W, lane);
+  Ring rg;
+  if (fwd) {
+    ring_init(rg, ring_lds + kRingWords, lat.fwd_stream + m.fwd_off, m.fwd_words, w);
+    ring_sweep(rg, m.fwd_steps, all_steps, alpha, th, ex, lat.fwd_perm + m.dp_off, w, lane);
+  } else {
+    ring_init(rg, ring_lds, lat.bwd_stream + m.bwd_off, m.bwd_words, w);
+    ring_sweep(rg, m.bwd_steps, all_steps, beta, th, ex, lat.bwd_perm + m.dp_off, w, lane);
   }
   __syncthreads();
   const float2 zme = beta[0];
@@ -448,7 +381,7 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
     if (logz64) logz64[b] = z;
     if (logz32) logz32[b] = (float)z;
   }
-  for (int i = tid; i < m.n_rows; i += NT) {
+  for (int i = tid; i < m.n_rows; i += 512) {
     if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
     if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
     if (beta_me) beta_me[m.row_off + i] = beta[i];
@@ -457,38 +390,29 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
     const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
     const int ez = __float_as_int(zme.y);
     const bool has_extra = ex.any();
-    const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
-    // 4 arcs per lane and iteration with 16-byte loads/stores on the aligned interior
-    const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
-    for (int a = v_begin + tid * 4; a < v_end; a += NT * 4) {
-      const int4 s4 = *reinterpret_cast<const int4 *>(lat.arc_src + a);
-      const int4 d4 = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
-      const int4 l4 = *reinterpret_cast<const int4 *>(lat.arc_label + a);
-      const int ss[4] = {s4.x, s4.y, s4.z, s4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w},
-                ll[4] = {l4.x, l4.y, l4.z, l4.w};
-      float pp[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pp[q] = (ss[q] != dd[q]) ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
-                                 : 0.0f;
-        if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
-      }
-      if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    }
-    // unaligned head and tail (at most 3 arcs each)
-    const int n_head = min(v_begin, a_end) - a_begin;
-    const int n_tail = (v_end >= v_begin) ? a_end - v_end : 0;
-    if (tid < n_head + n_tail) {
-      const int a = tid < n_head ? a_begin + tid : v_end + (tid - n_head);
+    for (int a = m.arc_off + tid; a < m.arc_off + m.n_arcs; a += 512) {
       const int s = lat.arc_src[a], d = lat.arc_dst[a], l = lat.arc_label[a];
-      const float p = (s != d) ? arc_posterior(alpha[s], beta[d], th[l], rz, ez, has_extra, ex, a) : 0.0f;
+      float p = 0.0f;
+      if (s != d) {
+        const float2 av = alpha[s], bv = beta[d], tw = th[l];
+        float mw = tw.x;
+        int ew = __float_as_int(tw.y);
+        if (has_extra) {
+          ME x = exp_split(ex.at(a));
+          mw *= x.m;
+          ew += x.e;
+        }
+        const float mm = (av.x * mw) * (bv.x * rz);
+        const int ee = __float_as_int(av.y) + ew + __float_as_int(bv.y) - ez;
+        p = ldexpf(mm, max(ee, -300));
+      }
       if (posterior) posterior[a] = p;
       if (grad_theta && p > 0.0f) atomicAdd(&gth[l], p);
     }
     if (grad_theta) {
       __syncthreads();
       float *g = grad_theta + (size_t)b * lat.vocab;
-      for (int l = tid; l < lat.vocab; l += NT) g[l] = gth[l];
+      for (int l = tid; l < lat.vocab; l += 512) g[l] = gth[l];
     }
   }
 }
@@ -523,7 +447,7 @@ __global__ __launch_bounds__(256) void k_viterbi(nfst_batch lat, nfst_scores sc,
     const bool accum = ((h0 >> 20) & 1u) != 0;
     const uint32_t *st = step + 2, *rec = st + ns + 1;
     const int spw = 64 >> kl, k = 1 << kl;
-    for (int base = wave * spw; base < ns; base += kViterbiWaves * spw) {
+    for (int base = wave * spw; base < ns; base += kSweepWaves * spw) {
       const int i = base + (lane >> kl), r = lane & (k - 1);
       float bv = kNegInf;
       int ba = 0x7fffffff;
@@ -847,7 +771,6 @@ int check_batch(const nfst_batch *lat) {
   if (lat->weighted && !lat->arc_w) return NFST_ERR_ARG;
   if (lat->max_rows > NFST_MAX_ROWS || lat->vocab > NFST_MAX_VOCAB) return NFST_ERR_LIMIT;
   if (lat->max_step_words <= 0 || lat->max_step_words > NFST_MAX_STEP_WORDS) return NFST_ERR_LIMIT;
-  if (lat->sweep_waves != 1 && lat->sweep_waves != 2 && lat->sweep_waves != 4) return NFST_ERR_ARG;
   if (((uintptr_t)lat->fwd_stream | (uintptr_t)lat->bwd_stream) & 15) return NFST_ERR_ARG;
   return NFST_OK;
 }
@@ -890,20 +813,10 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  const int64_t lds = (((int64_t)lat->max_rows + 1) / 2 * 2 + ((int64_t)lat->vocab + 1) / 2 * 2) * 8 +
-                      (int64_t)kRingWords * 4;
-#define NFST_LAUNCH_BWD(W)                                                                              \
-  {                                                                                                     \
-    if ((rc = set_lds(k_backward<W>, lds))) return rc;                                                  \
-    hipLaunchKernelGGL(k_backward<W>, dim3(lat->n_lattices), dim3(W * 64), (size_t)lds,                 \
-                       (hipStream_t)stream, *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me); \
-  }
-  switch (lat->sweep_waves) {
-    case 1: NFST_LAUNCH_BWD(1) break;
-    case 2: NFST_LAUNCH_BWD(2) break;
-    default: NFST_LAUNCH_BWD(4) break;
-  }
-#undef NFST_LAUNCH_BWD
+  const int64_t lds = (((int64_t)lat->max_rows + 1) / 2 * 2 + ((int64_t)lat->vocab + 1) / 2 * 2) * 8 + (int64_t)kRingWords * 4;
+  if ((rc = set_lds(k_backward, lds))) return rc;
+  hipLaunchKernelGGL(k_backward, dim3(lat->n_lattices), dim3(256), (size_t)lds, (hipStream_t)stream,
+                     *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me);
   return hip_status(hipGetLastError());
 }
 
@@ -913,22 +826,11 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
-  if (((uintptr_t)lat->arc_src | (uintptr_t)lat->arc_dst | (uintptr_t)lat->arc_label) & 15) return NFST_ERR_ARG;
   const int64_t lds = nfst_lds_bytes(lat);
-#define NFST_LAUNCH_FB(W)                                                                               \
-  {                                                                                                     \
-    if ((rc = set_lds(k_forward_backward<W>, lds))) return rc;                                          \
-    hipLaunchKernelGGL(k_forward_backward<W>, dim3(lat->n_lattices), dim3(FbGeom<W>::kThreads),         \
-                       (size_t)lds, (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64,      \
-                       logz32, posterior, grad_theta, (float2 *)beta_me);                               \
-  }
-  switch (lat->sweep_waves) {
-    case 1: NFST_LAUNCH_FB(1) break;
-    case 2: NFST_LAUNCH_FB(2) break;
-    default: NFST_LAUNCH_FB(4) break;
-  }
-#undef NFST_LAUNCH_FB
+  if ((rc = set_lds(k_forward_backward, lds))) return rc;
+  hipLaunchKernelGGL(k_forward_backward, dim3(lat->n_lattices), dim3(512), (size_t)lds,
+                     (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64, logz32,
+                     posterior, grad_theta, (float2 *)beta_me);
   return hip_status(hipGetLastError());
 }
 
