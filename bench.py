@@ -80,8 +80,7 @@ def main():
     ap.add_argument("--lattices-per-gpu", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--lanes-policy", type=int, default=0)
-    ap.add_argument("--sweep-waves", type=int, default=0, help="waves per sweep direction (0 = packer's choice)")
+    ap.add_argument("--slots", type=int, default=0, help="arc slots per lane of a tile (0 = packer's choice)")
     ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
@@ -112,7 +111,7 @@ def main():
     lats = synth.bench_batch(B, first_seed=1234 + rank * B, width=args.width)
     theta_np = synth.label_scores(1, 256)
     t0 = time.perf_counter()
-    lat = LatticeBatch.from_synth(lats, lanes_policy=args.lanes_policy, sweep_waves=args.sweep_waves)
+    lat = LatticeBatch.from_synth(lats, slots_per_lane=args.slots)
     pack_s = time.perf_counter() - t0
     lat = lat.to(dev)
     theta = torch.from_numpy(theta_np).to(dev)
@@ -180,7 +179,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {B} synthetic lattices per GPU, ~2k states / ~20k arcs "
                                    f"(layer width {args.width}), alpha+beta+logZ+arc posteriors",
                        "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
-                       "max_depth": int(lat.depth.max()), "sweep_waves": int(lat.sweep_waves), "loss": float(loss.item()), "host_pack_s": pack_s},
+                       "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": float(loss.item()), "host_pack_s": pack_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_forward_backward", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},

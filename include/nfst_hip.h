@@ -70,8 +70,7 @@ extern "C" {
 
 /* limits of the LDS-resident kernels */
 #define NFST_MAX_ROWS 8192     /* states per lattice incl. sink (alpha+beta live in LDS) */
-#define NFST_MAX_VOCAB 32768   /* labels are packed in 16 bits of an arc record */
-#define NFST_MAX_STEP_WORDS 512 /* a step is at most one 2 KiB block of the 16 KiB LDS ring */
+#define NFST_MAX_VOCAB 32767   /* labels + the null label are packed in 16 bits of an arc record */
 
 /* per-lattice metadata: NFST_META_WORDS int32 each, see DESIGN.md */
 #define NFST_META_WORDS 16
@@ -79,17 +78,18 @@ extern "C" {
 #define NFST_META_N_ROWS 1     /* rows of this lattice (S+1; padded rows included) */
 #define NFST_META_ARC_OFF 2    /* first canonical arc */
 #define NFST_META_N_ARCS 3     /* canonical arcs (incl. self loops) */
-#define NFST_META_FWD_OFF 4    /* word offset of the alpha (by-destination) stream */
-#define NFST_META_FWD_STEPS 5
-#define NFST_META_BWD_OFF 6    /* word offset of the beta (by-source) stream */
-#define NFST_META_BWD_STEPS 7
+#define NFST_META_FWD_OFF 4    /* word offset of the alpha (by-destination) tile program */
+#define NFST_META_FWD_TILES 5
+#define NFST_META_BWD_OFF 6    /* word offset of the beta (by-source) tile program */
+#define NFST_META_BWD_TILES 7
 #define NFST_META_SINK 8       /* sink state id */
 #define NFST_META_N_REACH 9    /* states reachable from 0 */
 #define NFST_META_DEPTH 10     /* longest path, in arcs */
-#define NFST_META_DP_OFF 11    /* first non-self-loop arc ordinal (perm arrays) */
-#define NFST_META_N_DP 12      /* non-self-loop arcs */
-#define NFST_META_FWD_WORDS 13
-#define NFST_META_BWD_WORDS 14
+#define NFST_META_N_DP 11      /* non-self-loop arcs */
+#define NFST_META_FWD_U 12     /* arc slots per lane of the alpha program: 1, 2 or 4 */
+#define NFST_META_BWD_U 13
+#define NFST_META_FWD_SLOT_OFF 14 /* first slot of this lattice in fwd_perm */
+#define NFST_META_BWD_SLOT_OFF 15
 
 /*
  * A packed batch of lattices.  All pointers are host memory when returned by
@@ -100,22 +100,22 @@ extern "C" {
  * Canonical arrays (user-facing): arcs of the states
  * reachable from state 0 in (state asc, label asc) order; values bit-exact with
  * nonzero(emission) / transition.  The sink's pad self loop is included.
- * Streams (engine-private): level-scheduled arc records, DESIGN.md section 3.
+ * Tile programs (engine-private): the level-scheduled sweeps, DESIGN.md section 3.
  */
 typedef struct nfst_batch {
   int32_t n_lattices;
   int32_t vocab;
   int32_t max_rows;        /* max n_rows over the batch */
-  int32_t max_steps;       /* max(fwd_steps, bwd_steps) over the batch */
+  int32_t max_tiles;       /* max tiles of one program over the batch */
   int32_t weighted;        /* arc_w holds the table's float weights */
-  int32_t max_step_words;  /* no step of a stream is longer (<= NFST_MAX_STEP_WORDS) */
-  int32_t sweep_waves;     /* waves per sweep direction the schedule was laid out for: 1, 2 or 4 */
   int32_t reserved0;
   int64_t total_rows;
   int64_t total_arcs;
   int64_t total_dp_arcs;
   int64_t fwd_words;
   int64_t bwd_words;
+  int64_t fwd_slots;
+  int64_t bwd_slots;
   const int32_t *meta;       /* [n_lattices * NFST_META_WORDS] */
   const int32_t *row_ptr;    /* [total_rows + n_lattices] absolute arc indices */
   const int32_t *arc_src;    /* [total_arcs] */
@@ -124,8 +124,8 @@ typedef struct nfst_batch {
   const float *arc_w;        /* [total_arcs] or NULL */
   const uint32_t *fwd_stream;/* [fwd_words] */
   const uint32_t *bwd_stream;/* [bwd_words] */
-  const int32_t *fwd_perm;   /* [total_dp_arcs] stream ordinal -> canonical arc */
-  const int32_t *bwd_perm;   /* [total_dp_arcs] */
+  const int32_t *fwd_perm;   /* [fwd_slots] tile slot -> canonical arc, -1 = empty slot */
+  const int32_t *bwd_perm;   /* [bwd_slots] */
 } nfst_batch;
 
 const char *nfst_strerror(int code);
@@ -139,9 +139,9 @@ typedef struct nfst_packed nfst_packed; /* opaque, owns host arrays */
 /* pack options; zero-initialise for defaults */
 typedef struct nfst_pack_opts {
   int32_t n_threads;       /* host threads over lattices (0 = hardware) */
-  int32_t max_step_words;  /* a step never exceeds this many stream words (0 = 512 = max) */
-  int32_t lanes_policy;    /* 0 = latency (fill the waves), 1 = throughput (few lanes/state) */
-  int32_t sweep_waves;     /* waves per sweep direction: 1, 2 or 4 (0 = choose from the level widths) */
+  int32_t slots_per_lane;  /* arc slots per lane of a tile: 1, 2 or 4 (0 = per lattice, fewest tiles) */
+  int32_t reserved0;
+  int32_t reserved1;
 } nfst_pack_opts;
 
 /*

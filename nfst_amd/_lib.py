@@ -11,12 +11,12 @@ import os
 import torch  # noqa: F401  -- first, so that torch's bundled HIP runtime is the one the process uses
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnfst_hip.so")
+LIB_PATH = os.environ.get("NFST_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libnfst_hip.so")  # override: diagnostics only
 
 META_WORDS = 16
-(META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_STEPS, META_BWD_OFF,
- META_BWD_STEPS, META_SINK, META_N_REACH, META_DEPTH, META_DP_OFF, META_N_DP, META_FWD_WORDS,
- META_BWD_WORDS) = range(15)
+(META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_TILES, META_BWD_OFF,
+ META_BWD_TILES, META_SINK, META_N_REACH, META_DEPTH, META_N_DP, META_FWD_U, META_BWD_U, META_FWD_SLOT_OFF,
+ META_BWD_SLOT_OFF) = range(16)
 
 OK = 0
 ERR_LENGTH = -9
@@ -34,10 +34,10 @@ class NfstError(RuntimeError):
 
 class Batch(C.Structure):
     _fields_ = [
-        ("n_lattices", C.c_int32), ("vocab", C.c_int32), ("max_rows", C.c_int32), ("max_steps", C.c_int32),
-        ("weighted", C.c_int32), ("max_step_words", C.c_int32), ("sweep_waves", C.c_int32), ("reserved0", C.c_int32),
+        ("n_lattices", C.c_int32), ("vocab", C.c_int32), ("max_rows", C.c_int32), ("max_tiles", C.c_int32),
+        ("weighted", C.c_int32), ("reserved0", C.c_int32),
         ("total_rows", C.c_int64), ("total_arcs", C.c_int64), ("total_dp_arcs", C.c_int64),
-        ("fwd_words", C.c_int64), ("bwd_words", C.c_int64),
+        ("fwd_words", C.c_int64), ("bwd_words", C.c_int64), ("fwd_slots", C.c_int64), ("bwd_slots", C.c_int64),
         ("meta", C.c_void_p), ("row_ptr", C.c_void_p), ("arc_src", C.c_void_p), ("arc_dst", C.c_void_p),
         ("arc_label", C.c_void_p), ("arc_w", C.c_void_p), ("fwd_stream", C.c_void_p), ("bwd_stream", C.c_void_p),
         ("fwd_perm", C.c_void_p), ("bwd_perm", C.c_void_p),
@@ -49,8 +49,8 @@ class Scores(C.Structure):
 
 
 class PackOpts(C.Structure):
-    _fields_ = [("n_threads", C.c_int32), ("max_step_words", C.c_int32), ("lanes_policy", C.c_int32),
-                ("sweep_waves", C.c_int32)]
+    _fields_ = [("n_threads", C.c_int32), ("slots_per_lane", C.c_int32), ("reserved0", C.c_int32),
+                ("reserved1", C.c_int32)]
 
 
 def _load():

@@ -28,7 +28,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-std=c++17",
-           "-I" + os.path.join(ROOT, "include"), "-Wall", "-Wextra", *SRC, "-o", OUT + ".tmp"]
+           "-I" + os.path.join(ROOT, "include"), "-Wall", "-Wextra", "-Wno-inline-asm", *SRC, "-o", OUT + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

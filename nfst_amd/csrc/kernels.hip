@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
-constexpr int kViterbiWaves = 4;        // waves of the Viterbi kernel
 constexpr float kNegInf = -__builtin_huge_valf();
 
 struct ME {
@@ -51,8 +50,10 @@ __device__ __forceinline__ void me_acc(float &M, int &E, float mt, int et) {
   M += ldexpf(mt, et - E);
 }
 
+// normalise a sum to mantissa in [0.5, 1).  A zero sum keeps mantissa 0 (frexp(0) = 0,
+// exponent 0): its exponent stays near kEZero, which never wins a max against a real
+// term, so no select is needed.
 __device__ __forceinline__ float2 me_pack(float M, int E) {
-  if (!(M > 0.0f)) return make_float2(0.0f, __int_as_float(kEZero));
   int ex;
   float mant = frexpf(M, &ex);
   return make_float2(mant, __int_as_float(E + ex));
@@ -69,19 +70,19 @@ __device__ __forceinline__ float me_log32(float2 v) {
 }
 
 struct Meta {
-  int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_steps, bwd_off, bwd_steps, sink, n_reach,
-      depth, dp_off, n_dp, fwd_words, bwd_words;
+  int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_tiles, bwd_off, bwd_tiles, sink, n_reach, depth, n_dp,
+      fwd_u, bwd_u, fwd_slot_off, bwd_slot_off;
 };
 __device__ __forceinline__ Meta load_meta(const int32_t *meta, int b) {
   const int32_t *m = meta + (size_t)b * NFST_META_WORDS;
   Meta r;
   r.row_off = m[NFST_META_ROW_OFF]; r.n_rows = m[NFST_META_N_ROWS];
   r.arc_off = m[NFST_META_ARC_OFF]; r.n_arcs = m[NFST_META_N_ARCS];
-  r.fwd_off = m[NFST_META_FWD_OFF]; r.fwd_steps = m[NFST_META_FWD_STEPS];
-  r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_steps = m[NFST_META_BWD_STEPS];
+  r.fwd_off = m[NFST_META_FWD_OFF]; r.fwd_tiles = m[NFST_META_FWD_TILES];
+  r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_tiles = m[NFST_META_BWD_TILES];
   r.sink = m[NFST_META_SINK]; r.n_reach = m[NFST_META_N_REACH]; r.depth = m[NFST_META_DEPTH];
-  r.dp_off = m[NFST_META_DP_OFF]; r.n_dp = m[NFST_META_N_DP];
-  r.fwd_words = m[NFST_META_FWD_WORDS]; r.bwd_words = m[NFST_META_BWD_WORDS];
+  r.n_dp = m[NFST_META_N_DP]; r.fwd_u = m[NFST_META_FWD_U]; r.bwd_u = m[NFST_META_BWD_U];
+  r.fwd_slot_off = m[NFST_META_FWD_SLOT_OFF]; r.bwd_slot_off = m[NFST_META_BWD_SLOT_OFF];
   return r;
 }
 
@@ -99,89 +100,31 @@ struct Extra {
   }
 };
 
-// ---------------------------------------------------------------- LDS ring (LDS-DMA)
-// A sweep consumes its stream strictly front to back and the stream does not
-// depend on the DP values, so it is prefetched far ahead: the sweep's W waves copy
-// 1-KiB chunks straight into a 16 KiB LDS ring with global_load_lds_dwordx4 (no
-// VGPR staging).  The ring is 8 blocks of 512 words (2 chunks each); chunk c is
-// issued by wave c % W and lives in slot c % 16.  A step is at most
-// NFST_MAX_STEP_WORDS = 512 words, so while the read offset is in block b a step
-// (plus the next step's 2-word header) touches blocks b .. b+2 only.  Protocol, run
-// by every wave when the offset enters block b ("crossing", at the top of a step,
-// i.e. after the barrier that ended the previous step):
-//   1. blocks < b are dead: issue the chunks this wave owns of block b+7 into them;
-//   2. counted wait: all of this wave's chunks of blocks <= b+3 have landed
-//      (blocks b+4 .. b+7 may stay in flight -- the constant vmcnt below);
-//   3. the barrier that ends this step publishes block b+3, one crossing before
-//      any wave can read it.
-// The prologue issues blocks 0..7 and waits for blocks 0..3 with the same constant.
-constexpr int kRingWords = 4096;
-constexpr int kRingMask = kRingWords - 1;
-constexpr int kChunkWords = 256;
-constexpr int kBlockShift = 9;  // 512-word blocks
-
-template <int W>
-struct Ring {
-  uint32_t *lds;      // ring base in LDS
-  const uint32_t *g;  // this lattice's stream (256-byte aligned)
-  int total_chunks;
-  int blk;            // block holding the current read offset
-  int w;              // this wave's index within the sweep
-};
-
-template <int W>
-__device__ __forceinline__ void ring_issue_block(const Ring<W> &r, int block, int lane) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int c = 2 * block + q;
-    if ((c % W) != r.w) continue;
-    uint32_t *dst = r.lds + (c & 15) * kChunkWords;
-    if (c < r.total_chunks) {
-      const uint32_t *src = r.g + (size_t)c * kChunkWords + lane * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    } else {
-      // past the end of the stream: a 4-byte-per-lane placeholder load into the (dead)
-      // slot keeps the wave's vmcnt sequence identical, so the constant waits stay exact
-      const uint32_t *src = r.g + lane;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-    }
-  }
-}
-
-template <int W>
-__device__ __forceinline__ void ring_wait() {
-  // chunks a wave may leave in flight: its share of 4 blocks (8 chunks)
-  if (W == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (W == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-}
-
-template <int W>
-__device__ __forceinline__ void ring_start(Ring<W> &r, uint32_t *lds, const uint32_t *g, int words, int w,
-                                           int lane) {
-  r.lds = lds; r.g = g; r.total_chunks = (words + kChunkWords - 1) / kChunkWords; r.blk = 0; r.w = w;
-  for (int b = 0; b < 8; ++b) ring_issue_block(r, b, lane);
-  ring_wait<W>();
-}
-
-template <int W>
-__device__ __forceinline__ void ring_advance(Ring<W> &r, int off, int lane) {
-  const int nb = off >> kBlockShift;
-  if (nb != r.blk) {  // a step is at most one block long: nb == blk + 1
-    r.blk = nb;
-    ring_issue_block(r, nb + 7, lane);
-    ring_wait<W>();
-  }
-}
-
-// workgroup barrier that does not drain the LDS-DMA queue (a __syncthreads() would
-// wait vmcnt(0)): this wave's LDS writes are complete, then s_barrier.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
+// ---------------------------------------------------------------- tile programs
+// A sweep is a "tile program" laid out by the host packer (pack.cpp, DESIGN.md
+// section 3): a sequence of fixed-size tiles, each one wave-wide unit of work --
+// 64 control words and 64*U arc records (U = 1, 2 or 4 slots per lane).  ONE wave
+// runs one sweep: its LDS accesses are ordered, a tile only reads states that an
+// earlier tile wrote, so a sweep needs no barrier at all, and the alpha and beta
+// sweeps of a lattice run as two independent waves of the workgroup.
+//
+// control word: [0:13) state id | [13] leader lane (stores the state's sum)
+//               [14] accumulate (continuation of a state with more than 64*U arcs)
+//               [16:19) g: the state's lanes are the 2^g-aligned group of 2^g lanes
+//               [20:23) largest g in this tile (same in every lane)
+// record:       [0:16) operand state | [16:32) label (vocab = the null label: weight 0)
+//
+// The program does not depend on DP values, so it is prefetched far ahead: every
+// iteration the wave copies one whole tile straight into a ring of kRingTiles tile
+// slots in LDS with global_load_lds (LDS-DMA, no VGPR staging): 16 B/lane covers the
+// first 256 words of a U=4 tile and a 4-B/lane load the last 64; U=2 and U=1 tiles are
+// three / two 4-B/lane loads.  While tile T is computed only tile T+1's words
+// are read from the ring, so slot T % kRingTiles is dead and receives tile
+// T + kRingTiles; a constant counted s_waitcnt vmcnt guarantees tile T+1 has landed.
+// There is no branch in the protocol: tiles past the end of the program re-load the
+// last tile into a slot nobody reads.
+constexpr int kRingTiles = 12;
+constexpr int kRingWords = kRingTiles * 320;  // 15 KiB per sweep (sized for U = 4)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
@@ -192,147 +135,193 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// All-reduce of an (M, E) partial sum over groups of 2^KL neighbouring lanes:
-// max of the exponents, one rescale, then the sum.  Quad permutes and half-row /
-// row mirrors are DPP modifiers (no LDS traffic); 32- and 64-lane groups finish with
-// shuffles.  Every lane of a group ends with bitwise the same (M, E).
-template <int KL>
-__device__ __forceinline__ void group_reduce(float &M, int &E) {
+// Segmented all-reduce of (M, E) partial sums: a lane whose state owns 2^g lanes takes
+// part in stages 0 .. g-1.  Stage partners: lane^1, lane^2 (quad permutes), 7-lane and
+// 15-lane mirrors inside a row (DPP modifiers, no LDS traffic), then lane^16 and
+// lane^32 (shuffles).  GMAX (the tile's largest g) bounds the stages executed.  All
+// lanes of a state end with bitwise the same (M, E): max of exponents, one rescale,
+// then the sum.
+// Segmented all-reduce of (M, E) partial sums: a lane whose state owns 2^g lanes takes
+// part in stages 0 .. g-1.  Stage partners: lane^1, lane^2 (quad permutes), 7-lane and
+// 15-lane mirrors inside a row (DPP modifiers, no LDS traffic), then lane^16 and
+// lane^32 (shuffles).  Stages 0..2 always run (one predicated select each, no
+// branch); stages 3..5 only when the tile's largest g needs them.  All lanes of a state
+// end with bitwise the same (M, E): max of exponents, one rescale, then the sum.
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_n(float &M, int &E, int g) {
   int Em = E;
-  if (KL >= 1) Em = max(Em, dpp_i<0xB1>(Em));   // quad_perm [1,0,3,2]
-  if (KL >= 2) Em = max(Em, dpp_i<0x4E>(Em));   // quad_perm [2,3,0,1]
-  if (KL >= 3) Em = max(Em, dpp_i<0x141>(Em));  // row_half_mirror
-  if (KL >= 4) Em = max(Em, dpp_i<0x140>(Em));  // row_mirror
-  if (KL >= 5) Em = max(Em, __shfl_xor(Em, 16));
-  if (KL >= 6) Em = max(Em, __shfl_xor(Em, 32));
-  if (KL >= 1) {
-    M = ldexpf(M, E - Em);
-    E = Em;
-  }
-  if (KL >= 1) M += dpp_f<0xB1>(M);
-  if (KL >= 2) M += dpp_f<0x4E>(M);
-  if (KL >= 3) M += dpp_f<0x141>(M);
-  if (KL >= 4) M += dpp_f<0x140>(M);
-  if (KL >= 5) M += __shfl_xor(M, 16);
-  if (KL >= 6) M += __shfl_xor(M, 32);
+  if (STAGES >= 1) { const int o = dpp_i<0xB1>(Em); Em = (g >= 1) ? max(Em, o) : Em; }
+  if (STAGES >= 2) { const int o = dpp_i<0x4E>(Em); Em = (g >= 2) ? max(Em, o) : Em; }
+  if (STAGES >= 3) { const int o = dpp_i<0x141>(Em); Em = (g >= 3) ? max(Em, o) : Em; }
+  if (STAGES >= 4) { const int o = dpp_i<0x140>(Em); Em = (g >= 4) ? max(Em, o) : Em; }
+  if (STAGES >= 5) { const int o = __shfl_xor(Em, 16); Em = (g >= 5) ? max(Em, o) : Em; }
+  if (STAGES >= 6) { const int o = __shfl_xor(Em, 32); Em = (g >= 6) ? max(Em, o) : Em; }
+  M = ldexpf(M, E - Em);
+  E = Em;
+  if (STAGES >= 1) { const float o = dpp_f<0xB1>(M); M = (g >= 1) ? M + o : M; }
+  if (STAGES >= 2) { const float o = dpp_f<0x4E>(M); M = (g >= 2) ? M + o : M; }
+  if (STAGES >= 3) { const float o = dpp_f<0x141>(M); M = (g >= 3) ? M + o : M; }
+  if (STAGES >= 4) { const float o = dpp_f<0x140>(M); M = (g >= 4) ? M + o : M; }
+  if (STAGES >= 5) { const float o = __shfl_xor(M, 16); M = (g >= 5) ? M + o : M; }
+  if (STAGES >= 6) { const float o = __shfl_xor(M, 32); M = (g >= 6) ? M + o : M; }
+}
+__device__ __forceinline__ void seg_reduce(float &M, int &E, int g, int gmax) {
+  // two complete variants: the shuffles of the wide one (LDS-routed, they drain the
+  // lgkm queue) must stay out of the common path
+  if (__builtin_expect(gmax > 3, 0)) seg_reduce_n<6>(M, E, g);
+  else seg_reduce_n<3>(M, E, g);
 }
 
-struct StepCtx {
-  const uint32_t *ring;
-  float2 *val;
-  const float2 *th;
-  Extra ex;
-  const int32_t *perm;  // + arc_base already applied
-  int st, rec, ns;
-  bool accum, has_extra;
+template <int U>
+struct TileRegs {
+  uint32_t ctl;
+  uint32_t rc[U];
 };
 
-__device__ __forceinline__ void arc_term(const StepCtx &c, int a, float &mt, int &et) {
-  const uint32_t rc = c.ring[(c.rec + a) & kRingMask];
-  const float2 tw = c.th[rc >> 16];
-  const float2 v = c.val[rc & 0xffffu];
-  float mw = tw.x;
-  int ew = __float_as_int(tw.y);
-  if (c.has_extra) {
-    ME x = exp_split(c.ex.at(c.perm[a]));
-    mw *= x.m;
-    ew += x.e;
+template <int U>
+__device__ __forceinline__ void tile_fetch(const uint32_t *ring, int tile_slot, int lane, TileRegs<U> &t) {
+  constexpr int ST = 64 * (1 + U);
+  const uint32_t *base = ring + tile_slot * ST;
+  t.ctl = base[lane];
+  const uint32_t *r = base + 64 + lane * U;
+  if (U == 4) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(r);
+    t.rc[0] = v.x; t.rc[1 % U] = v.y; t.rc[2 % U] = v.z; t.rc[3 % U] = v.w;
+  } else if (U == 2) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(r);
+    t.rc[0] = v.x; t.rc[1 % U] = v.y;
+  } else {
+    t.rc[0] = r[0];
   }
-  mt = mw * v.x;
-  et = ew + __float_as_int(v.y);
 }
 
-// The tiles of one step owned by wave w of W: 2^KL lanes per state, 64 >> KL states
-// per tile; the first two arcs of a lane are summed with one shared exponent, the
-// rest (rare: the packer keeps lanes at <= 2 arcs when it can) by the online rule.
-template <int KL, int W>
-__device__ __forceinline__ void step_tiles(const StepCtx &c, int w, int lane) {
-  constexpr int k = 1 << KL;
-  constexpr int spw = 64 >> KL;
-  for (int base = w * spw; base < c.ns; base += W * spw) {
-    const int i = base + (lane >> KL);
-    const int r = lane & (k - 1);
-    float M = 0.0f;
-    int E = kEZero;
-    uint32_t sid = 0;
-    if (i < c.ns) {
-      const uint32_t w0 = c.ring[(c.st + i) & kRingMask], w1 = c.ring[(c.st + i + 1) & kRingMask];
-      sid = w0 & 0xffffu;
-      const int a0 = (int)(w0 >> 16) + r, a1 = (int)(w1 >> 16);
-      float m0 = 0.0f, m1 = 0.0f;
-      int e0 = kEZero, e1 = kEZero;
-      if (a0 < a1) arc_term(c, a0, m0, e0);
-      if (a0 + k < a1) arc_term(c, a0 + k, m1, e1);
-      E = max(e0, e1);
-      M = ldexpf(m0, e0 - E) + ldexpf(m1, e1 - E);
-      for (int a = a0 + 2 * k; a < a1; a += k) {
-        float mt;
-        int et;
-        arc_term(c, a, mt, et);
-        me_acc(M, E, mt, et);
-      }
+// LDS-DMA (global_load_lds_*): lane i's `bytes` go to LDS address m0 + i*bytes.  Issued
+// from inline asm on purpose: the compiler then keeps no record of a pending LDS-DMA and
+// does not put s_waitcnt vmcnt(0) in front of every LDS access of the sweep; the counted
+// waits are placed by hand (tile_wait).  Callers must not rely on compiler-generated
+// vmcnt for these loads.
+__device__ __forceinline__ void lds_dma16(const uint32_t *gsrc, uint32_t *lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gsrc) : "m0", "memory");
+}
+__device__ __forceinline__ void lds_dma4(const uint32_t *gsrc, uint32_t *lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(l), "v"(gsrc) : "m0", "memory");
+}
+
+// copy of tile `tile` of the program g into ring slot `slot`
+template <int U>
+__device__ __forceinline__ void tile_issue(const uint32_t *g, int tile, uint32_t *ring, int slot, int lane) {
+  constexpr int ST = 64 * (1 + U);
+  const uint32_t *src = g + (size_t)tile * ST;
+  uint32_t *dst = ring + slot * ST;
+  if (U == 4) {
+    lds_dma16(src + lane * 4, dst);
+    lds_dma4(src + 256 + lane, dst + 256);
+  } else if (U == 2) {
+    lds_dma4(src + lane, dst);
+    lds_dma4(src + 64 + lane, dst + 64);
+    lds_dma4(src + 128 + lane, dst + 128);
+  } else {
+    lds_dma4(src + lane, dst);
+    lds_dma4(src + 64 + lane, dst + 64);
+  }
+}
+template <int U>
+__device__ __forceinline__ void tile_wait() {
+  // LDS-DMA loads that may stay in flight: those of kRingTiles - 1 tiles
+#ifdef NFST_EXP_NOWAIT
+  return;
+#endif
+  if (U == 2) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+}
+
+// One sum-product sweep, run by ONE wave.  g: the lattice's tile program (256-byte
+// aligned), ring: kRingWords of LDS owned by this wave, val: alpha or beta (LDS), th:
+// exp-split label weights incl. the null label (LDS), perm: slot -> canonical arc of
+// this program (only read when there are per-arc extras, EXTRA = true).
+template <int U, bool EXTRA>
+__device__ __forceinline__ void tile_sweep(const uint32_t *g, int n_tiles, uint32_t *ring, float2 *val,
+                                           const float2 *th, const Extra ex, const int32_t *__restrict__ perm,
+                                           int lane) {
+  if (n_tiles <= 0) return;
+  const int last = n_tiles - 1;
+  for (int T = 0; T < kRingTiles; ++T) tile_issue<U>(g, min(T, last), ring, T, lane);
+  tile_wait<U>();  // tile 0 (and more) has landed
+  TileRegs<U> cur;
+  tile_fetch<U>(ring, 0, lane, cur);
+  int slot = 0;  // T % kRingTiles
+  for (int T = 0; T < n_tiles; ++T) {
+    const int slot_next = (slot + 1 == kRingTiles) ? 0 : slot + 1;
+    // --- gathers of this tile
+    float2 tw[U], vv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      tw[j] = th[cur.rc[j] >> 16];
+      vv[j] = val[cur.rc[j] & 0xffffu];
     }
-    group_reduce<KL>(M, E);
-    if (i < c.ns && r == 0) {
-      if (c.accum) {
-        const float2 old = c.val[sid];
+    // --- ring: this tile's slot is dead (its words are in registers): refill it, then
+    // make sure tile T+1 has landed and fetch its static data
+#ifndef NFST_EXP_NODMA
+    tile_issue<U>(g, min(T + kRingTiles, last), ring, slot, lane);
+#endif
+    tile_wait<U>();
+    TileRegs<U> nxt;
+    tile_fetch<U>(ring, slot_next, lane, nxt);
+    // --- this lane's partial sum with one shared exponent
+    float mt[U];
+    int et[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      float mw = tw[j].x;
+      int ew = __float_as_int(tw[j].y);
+      if (EXTRA) {
+        const int arc = perm[(size_t)T * (64 * U) + lane * U + j];
+        if (arc >= 0) {
+          ME x = exp_split(ex.at(arc));
+          mw *= x.m;
+          ew += x.e;
+        }
+      }
+      mt[j] = mw * vv[j].x;
+      et[j] = ew + __float_as_int(vv[j].y);
+    }
+    int E = et[0];
+#pragma unroll
+    for (int j = 1; j < U; ++j) E = max(E, et[j]);
+    float M = ldexpf(mt[0], et[0] - E);
+#pragma unroll
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
+    // --- reduce over the state's lanes, normalise, store
+    const int gl = (int)((cur.ctl >> 16) & 7u);
+    const int gmax = (int)((__builtin_amdgcn_readfirstlane(cur.ctl) >> 20) & 7u);
+    seg_reduce(M, E, gl, gmax);
+    if (cur.ctl & (1u << 13)) {
+      const uint32_t sid = cur.ctl & 0x1fffu;
+      if (cur.ctl & (1u << 14)) {
+        const float2 old = val[sid];
         me_acc(M, E, old.x, __float_as_int(old.y));
       }
-      c.val[sid] = me_pack(M, E);
+      val[sid] = me_pack(M, E);
     }
-  }
-}
-
-// One sum-product sweep over one direction's stream, run by W waves (index w) of the
-// workgroup.  With W > 1 the waves meet at one barrier per step and every wave of the
-// workgroup must call lds_barrier() exactly n_barriers + 1 times; with W == 1 a sweep
-// is a single wave, its LDS accesses are ordered, and there is no barrier at all.
-template <int W>
-__device__ __forceinline__ void ring_sweep(const uint32_t *g, int words, uint32_t *ring_lds, int my_steps,
-                                           int n_barriers, float2 *val, const float2 *th, const Extra ex,
-                                           const int32_t *__restrict__ perm, int w, int lane) {
-  Ring<W> rg;
-  ring_start(rg, ring_lds, g, words, w, lane);
-  if (W > 1) lds_barrier();
-  StepCtx c;
-  c.ring = ring_lds; c.val = val; c.th = th; c.ex = ex; c.has_extra = ex.any();
-  int off = 0, arc_base = 0;
-  uint32_t h0 = 0, na_u = 0;
-  if (my_steps > 0) {
-    h0 = __builtin_amdgcn_readfirstlane(ring_lds[0]);
-    na_u = __builtin_amdgcn_readfirstlane(ring_lds[1]);
-  }
-  for (int t = 0; t < n_barriers; ++t) {
-    if (t < my_steps) {
-      const int na = (int)na_u;
-      const int kl = (int)((h0 >> 16) & 0xfu);
-      c.ns = (int)(h0 & 0xffffu);
-      c.accum = ((h0 >> 20) & 1u) != 0;
-      c.st = off + 2;
-      c.rec = c.st + c.ns + 1;
-      c.perm = perm + arc_base;
-      const int next_off = c.rec + na;
-      ring_advance(rg, off, lane);
-      // header of the next step: static data that has already landed
-      const uint32_t nh0 = ring_lds[next_off & kRingMask];
-      const uint32_t nna = ring_lds[(next_off + 1) & kRingMask];
-      switch (kl) {
-        case 0: step_tiles<0, W>(c, w, lane); break;
-        case 1: step_tiles<1, W>(c, w, lane); break;
-        case 2: step_tiles<2, W>(c, w, lane); break;
-        case 3: step_tiles<3, W>(c, w, lane); break;
-        case 4: step_tiles<4, W>(c, w, lane); break;
-        case 5: step_tiles<5, W>(c, w, lane); break;
-        default: step_tiles<6, W>(c, w, lane); break;
-      }
-      off = next_off;
-      arc_base += na;
-      h0 = __builtin_amdgcn_readfirstlane(nh0);
-      na_u = __builtin_amdgcn_readfirstlane(nna);
-    }
-    if (W > 1) lds_barrier();
+    cur = nxt;
+    slot = slot_next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight
+}
+
+__device__ __forceinline__ void tile_sweep_u(int U, const uint32_t *g, int n_tiles, uint32_t *ring, float2 *val,
+                                             const float2 *th, const Extra ex, const int32_t *perm, int lane) {
+  if (ex.any()) {
+    if (U == 4) tile_sweep<4, true>(g, n_tiles, ring, val, th, ex, perm, lane);
+    else if (U == 2) tile_sweep<2, true>(g, n_tiles, ring, val, th, ex, perm, lane);
+    else tile_sweep<1, true>(g, n_tiles, ring, val, th, ex, perm, lane);
+  } else {
+    if (U == 4) tile_sweep<4, false>(g, n_tiles, ring, val, th, ex, perm, lane);
+    else if (U == 2) tile_sweep<2, false>(g, n_tiles, ring, val, th, ex, perm, lane);
+    else tile_sweep<1, false>(g, n_tiles, ring, val, th, ex, perm, lane);
+  }
 }
 
 __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64_t stride, int b,
@@ -342,31 +331,45 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
     ME x = exp_split(t[l]);
     th[l] = make_float2(x.m, __int_as_float(x.e));
   }
+  if (tid == 0) th[V] = make_float2(0.0f, __int_as_float(kEZero));  // the null label of empty slots
 }
 
+// ------------------------------------------------------------------ LDS layout
+// [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V + null label)]
+// [label histogram: v4 float][ring 0: 3840 words][ring 1: 3840 words]   (all 16-B aligned)
+struct LdsPlan {
+  int rows2, v2, v4;
+  __host__ __device__ LdsPlan(int max_rows, int vocab)
+      : rows2((max_rows + 1) & ~1), v2((vocab + 2) & ~1), v4((vocab + 3) & ~3) {}
+  __host__ __device__ int64_t fb_bytes() const { return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)kRingWords * 4; }
+  __host__ __device__ int64_t bwd_bytes() const { return ((int64_t)rows2 + v2) * 8 + (int64_t)kRingWords * 4; }
+};
+
+constexpr int kFbThreads = 256;  // wave 0: beta sweep, wave 1: alpha sweep, all 4: init + posteriors
+
 // ------------------------------------------------------------------ backward only
-// W waves sweep the by-source stream from the sink (block = max(W, 2) * 64 threads...
-// exactly W * 64 threads).
-template <int W>
-__global__ __launch_bounds__(W * 64) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
-                                                     double *logz64, float *logz32, float2 *beta_me) {
+// Wave 0 sweeps the by-source program from the sink; the other waves help with the
+// initialisation and the outputs.
+__global__ __launch_bounds__(kFbThreads) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
+                                                         double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = W * 64;
+  constexpr int NT = kFbThreads;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
-  const int rows2 = (lat.max_rows + 1) & ~1;
+  const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *beta = lds;
-  float2 *th = lds + rows2;
-  uint32_t *ring_lds = (uint32_t *)(th + ((lat.vocab + 1) & ~1));
+  float2 *th = lds + plan.rows2;
+  uint32_t *ring = (uint32_t *)(th + plan.v2);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
   if (tid == 0) beta[m.sink] = make_float2(0.5f, __int_as_float(1));
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, m.bwd_steps, beta, th, ex,
-                lat.bwd_perm + m.dp_off, w, lane);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wv == 0)
+    tile_sweep_u(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, beta, th, ex,
+                 lat.bwd_perm + m.bwd_slot_off, lane);
   __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -380,15 +383,6 @@ __global__ __launch_bounds__(W * 64) void k_backward(nfst_batch lat, nfst_scores
 }
 
 // ------------------------------------------------------------------ forward-backward
-// Waves [0, W) run the beta sweep and waves [W, 2W) the alpha sweep, concurrently;
-// then every wave of the block streams the canonical arcs once for the posteriors.
-// W = 1: 256-thread block, the two sweeps are single waves that never synchronise
-// (the other two waves wait at the barrier before the posterior pass).
-template <int W>
-struct FbGeom {
-  static constexpr int kThreads = (2 * W * 64 < 256) ? 256 : 2 * W * 64;
-};
-
 __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv, const float2 tw, float rz,
                                                int ez, bool has_extra, const Extra &ex, int a) {
   float mw = tw.x;
@@ -403,22 +397,23 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
   return ldexpf(mm, max(ee, -300));
 }
 
-template <int W>
-__global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
+// Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
+// synchronisation between them; after the one barrier that follows, all four waves
+// stream the canonical arcs once for the posteriors.
+__global__ __launch_bounds__(kFbThreads) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = FbGeom<W>::kThreads;
+  constexpr int NT = kFbThreads;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
-  const int rows2 = (lat.max_rows + 1) & ~1;
-  const int v4 = (lat.vocab + 3) & ~3;
+  const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *alpha = lds;
-  float2 *beta = lds + rows2;
-  float2 *th = lds + 2 * rows2;
-  float *gth = (float *)(th + v4);             // [V] label histogram (only if grad_theta)
-  uint32_t *ring_lds = (uint32_t *)(gth + v4);  // two 16 KiB rings: beta stream, alpha stream
+  float2 *beta = lds + plan.rows2;
+  float2 *th = lds + 2 * plan.rows2;
+  float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
+  uint32_t *ring = (uint32_t *)(gth + plan.v4);
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -433,14 +428,12 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int all_steps = max(m.fwd_steps, m.bwd_steps);
-  if (wv < W) {
-    ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, all_steps, beta, th, ex,
-                  lat.bwd_perm + m.dp_off, wv, lane);
-  } else if (wv < 2 * W) {
-    ring_sweep<W>(lat.fwd_stream + m.fwd_off, m.fwd_words, ring_lds + kRingWords, m.fwd_steps, all_steps,
-                  alpha, th, ex, lat.fwd_perm + m.dp_off, wv - W, lane);
-  }
+  if (wv == 0)
+    tile_sweep_u(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, beta, th, ex,
+                 lat.bwd_perm + m.bwd_slot_off, lane);
+  else if (wv == 1)
+    tile_sweep_u(m.fwd_u, lat.fwd_stream + m.fwd_off, m.fwd_tiles, ring + kRingWords, alpha, th, ex,
+                 lat.fwd_perm + m.fwd_slot_off, lane);
   __syncthreads();
   const float2 zme = beta[0];
   if (tid == 0) {
@@ -480,98 +473,91 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
     const int n_tail = (v_end >= v_begin) ? a_end - v_end : 0;
     if (tid < n_head + n_tail) {
       const int a = tid < n_head ? a_begin + tid : v_end + (tid - n_head);
-      const int s = lat.arc_src[a], d = lat.arc_dst[a], l = lat.arc_label[a];
-      const float p = (s != d) ? arc_posterior(alpha[s], beta[d], th[l], rz, ez, has_extra, ex, a) : 0.0f;
+      const int s0 = lat.arc_src[a], d0 = lat.arc_dst[a], l0 = lat.arc_label[a];
+      const float p = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[l0], rz, ez, has_extra, ex, a) : 0.0f;
       if (posterior) posterior[a] = p;
-      if (grad_theta && p > 0.0f) atomicAdd(&gth[l], p);
+      if (grad_theta && p > 0.0f) atomicAdd(&gth[l0], p);
     }
     if (grad_theta) {
       __syncthreads();
-      float *g = grad_theta + (size_t)b * lat.vocab;
-      for (int l = tid; l < lat.vocab; l += NT) g[l] = gth[l];
+      float *gout = grad_theta + (size_t)b * lat.vocab;
+      for (int l = tid; l < lat.vocab; l += NT) gout[l] = gth[l];
     }
   }
 }
 
 // ------------------------------------------------------------------ Viterbi
-// max-plus sweep over the by-source stream; float32 values, canonical arc back
-// pointers; thread 0 then walks the best path.
-__global__ __launch_bounds__(256) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
-                                                 int32_t *paths, int32_t *path_arcs,
-                                                 int32_t *lengths, int max_len, int pad) {
+// max-plus run of the by-source tile program by one wave (float32 values, canonical
+// arc back pointers in LDS; the program is read straight from global memory -- this
+// kernel is not on the benchmark path), then lane 0 walks the best path.  Ties keep
+// the arc with the smallest canonical id, i.e. the smallest label.
+__device__ __forceinline__ void vit_take(float &bv, int &ba, float ov, int oa) {
+  if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; }
+}
+
+__global__ __launch_bounds__(64) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
+                                                int32_t *paths, int32_t *path_arcs,
+                                                int32_t *lengths, int max_len, int pad) {
   extern __shared__ float2 lds[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, lane = threadIdx.x;
   const Meta m = load_meta(lat.meta, b);
   float *v = (float *)lds;
   int *bp = (int *)(v + lat.max_rows);
-  float *th = (float *)(bp + lat.max_rows);
-  for (int i = tid; i < m.n_rows; i += 256) { v[i] = kNegInf; bp[i] = -1; }
+  for (int i = lane; i < m.n_rows; i += 64) { v[i] = kNegInf; bp[i] = -1; }
+  __syncthreads();
+  if (lane == 0) v[m.sink] = 0.0f;
+  __syncthreads();
   const float *tg = sc.theta + (size_t)sc.theta_stride * b;
-  for (int l = tid; l < lat.vocab; l += 256) th[l] = tg[l];
-  __syncthreads();
-  if (tid == 0) v[m.sink] = 0.0f;
-  __syncthreads();
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
-  const uint32_t *stream = lat.bwd_stream + m.bwd_off;
-  const int32_t *perm = lat.bwd_perm + m.dp_off;
-  int off = 0, arc_base = 0;
-  for (int t = 0; t < m.bwd_steps; ++t) {
-    const uint32_t *step = stream + off;
-    const uint32_t h0 = __builtin_amdgcn_readfirstlane(step[0]);
-    const int na = (int)__builtin_amdgcn_readfirstlane(step[1]);
-    const int ns = (int)(h0 & 0xffffu), kl = (int)((h0 >> 16) & 0xfu);
-    const bool accum = ((h0 >> 20) & 1u) != 0;
-    const uint32_t *st = step + 2, *rec = st + ns + 1;
-    const int spw = 64 >> kl, k = 1 << kl;
-    for (int base = wave * spw; base < ns; base += kViterbiWaves * spw) {
-      const int i = base + (lane >> kl), r = lane & (k - 1);
-      float bv = kNegInf;
-      int ba = 0x7fffffff;
-      uint32_t sid = 0;
-      if (i < ns) {
-        const uint32_t w0 = st[i], w1 = st[i + 1];
-        sid = w0 & 0xffffu;
-        for (int a = (int)(w0 >> 16) + r; a < (int)(w1 >> 16); a += k) {
-          const uint32_t rc = rec[a];
-          const int ca = perm[arc_base + a];
-          float s = th[rc >> 16];
-          if (arc_w) s += arc_w[ca];
-          if (sc.arc_scores) s += sc.arc_scores[ca];
-          const float c = s + v[rc & 0xffffu];
-          if (c > bv) { bv = c; ba = ca; }
-        }
-      }
-      for (int d = 1; d < k; d <<= 1) {
-        const float ov = __shfl_xor(bv, d);
-        const int oa = __shfl_xor(ba, d);
-        if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; }
-      }
-      if (i < ns && r == 0) {
-        if (accum) {
-          const float ov = v[sid];
-          const int oa = bp[sid];
-          if (ov > bv || (ov == bv && oa >= 0 && oa < ba)) { bv = ov; ba = oa; }
-        }
-        v[sid] = bv;
-        bp[sid] = (ba == 0x7fffffff) ? -1 : ba;
-      }
+  const int U = m.bwd_u, ST = 64 * (1 + U);
+  const uint32_t *prog = lat.bwd_stream + m.bwd_off;
+  const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
+  constexpr int kNone = 0x7fffffff;
+  for (int T = 0; T < m.bwd_tiles; ++T) {
+    const uint32_t ctl = prog[(size_t)T * ST + lane];
+    float bv = kNegInf;
+    int ba = kNone;
+    for (int j = 0; j < U; ++j) {
+      const int ca = perm[(size_t)T * 64 * U + lane * U + j];
+      if (ca < 0) continue;
+      const uint32_t rc = prog[(size_t)T * ST + 64 + lane * U + j];
+      float s0 = tg[rc >> 16];
+      if (arc_w) s0 += arc_w[ca];
+      if (sc.arc_scores) s0 += sc.arc_scores[ca];
+      vit_take(bv, ba, s0 + v[rc & 0xffffu], ca);
     }
-    off += 2 + ns + 1 + na;
-    arc_base += na;
-    __syncthreads();
+    const int gl = (int)((ctl >> 16) & 7u);
+    for (int st = 0; st < 6; ++st) {
+      int partner;
+      if (st == 0) partner = lane ^ 1;
+      else if (st == 1) partner = lane ^ 2;
+      else if (st == 2) partner = (lane & ~7) | (7 - (lane & 7));
+      else if (st == 3) partner = (lane & ~15) | (15 - (lane & 15));
+      else partner = lane ^ (1 << st);
+      const float ov = __shfl(bv, partner);
+      const int oa = __shfl(ba, partner);
+      if (gl > st) vit_take(bv, ba, ov, oa);
+    }
+    if (ctl & (1u << 13)) {
+      const uint32_t sid = ctl & 0x1fffu;
+      if ((ctl & (1u << 14)) && bp[sid] >= 0) vit_take(bv, ba, v[sid], bp[sid]);
+      v[sid] = bv;
+      bp[sid] = (ba == kNone) ? -1 : ba;
+    }
+    __syncthreads();  // single wave: orders the LDS stores before the next tile's loads
   }
-  if (tid == 0) {
+  if (lane == 0) {
     best[b] = v[0];
-    int s = 0, len = 0;
-    while (s != m.sink && len < max_len) {
-      const int a = bp[s];
+    int s0 = 0, len = 0;
+    while (s0 != m.sink && len < max_len) {
+      const int a = bp[s0];
       if (a < 0) break;
       paths[(size_t)b * max_len + len] = lat.arc_label[a];
       if (path_arcs) path_arcs[(size_t)b * max_len + len] = a;
       ++len;
-      s = lat.arc_dst[a];
+      s0 = lat.arc_dst[a];
     }
-    lengths[b] = (s == m.sink) ? len : -1;
+    lengths[b] = (s0 == m.sink) ? len : -1;
     for (int j = len; j < max_len; ++j) {
       paths[(size_t)b * max_len + j] = pad;
       if (path_arcs) path_arcs[(size_t)b * max_len + j] = -1;
@@ -843,11 +829,9 @@ int check_batch(const nfst_batch *lat) {
   if (!lat || lat->n_lattices <= 0 || lat->vocab <= 0 || lat->max_rows <= 0) return NFST_ERR_ARG;
   if (!lat->meta || !lat->row_ptr || !lat->fwd_stream || !lat->bwd_stream) return NFST_ERR_ARG;
   if (lat->total_arcs > 0 && (!lat->arc_src || !lat->arc_dst || !lat->arc_label)) return NFST_ERR_ARG;
-  if (lat->total_dp_arcs > 0 && (!lat->fwd_perm || !lat->bwd_perm)) return NFST_ERR_ARG;
+  if ((lat->fwd_slots > 0 && !lat->fwd_perm) || (lat->bwd_slots > 0 && !lat->bwd_perm)) return NFST_ERR_ARG;
   if (lat->weighted && !lat->arc_w) return NFST_ERR_ARG;
   if (lat->max_rows > NFST_MAX_ROWS || lat->vocab > NFST_MAX_VOCAB) return NFST_ERR_LIMIT;
-  if (lat->max_step_words <= 0 || lat->max_step_words > NFST_MAX_STEP_WORDS) return NFST_ERR_LIMIT;
-  if (lat->sweep_waves != 1 && lat->sweep_waves != 2 && lat->sweep_waves != 4) return NFST_ERR_ARG;
   if (((uintptr_t)lat->fwd_stream | (uintptr_t)lat->bwd_stream) & 15) return NFST_ERR_ARG;
   return NFST_OK;
 }
@@ -881,8 +865,7 @@ int nfst_device_available(void) {
 
 int64_t nfst_lds_bytes(const nfst_batch *lat) {
   if (!lat) return NFST_ERR_ARG;
-  const int64_t rows2 = (lat->max_rows + 1) & ~1, v4 = (lat->vocab + 3) & ~3;
-  return (2 * rows2 + v4) * 8 + v4 * 4 + 2 * (int64_t)kRingWords * 4;
+  return LdsPlan(lat->max_rows, lat->vocab).fb_bytes();
 }
 
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta, double *logz64,
@@ -890,20 +873,10 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  const int64_t lds = (((int64_t)lat->max_rows + 1) / 2 * 2 + ((int64_t)lat->vocab + 1) / 2 * 2) * 8 +
-                      (int64_t)kRingWords * 4;
-#define NFST_LAUNCH_BWD(W)                                                                              \
-  {                                                                                                     \
-    if ((rc = set_lds(k_backward<W>, lds))) return rc;                                                  \
-    hipLaunchKernelGGL(k_backward<W>, dim3(lat->n_lattices), dim3(W * 64), (size_t)lds,                 \
-                       (hipStream_t)stream, *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me); \
-  }
-  switch (lat->sweep_waves) {
-    case 1: NFST_LAUNCH_BWD(1) break;
-    case 2: NFST_LAUNCH_BWD(2) break;
-    default: NFST_LAUNCH_BWD(4) break;
-  }
-#undef NFST_LAUNCH_BWD
+  const int64_t lds = LdsPlan(lat->max_rows, lat->vocab).bwd_bytes();
+  if ((rc = set_lds(k_backward, lds))) return rc;
+  hipLaunchKernelGGL(k_backward, dim3(lat->n_lattices), dim3(kFbThreads), (size_t)lds, (hipStream_t)stream,
+                     *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me);
   return hip_status(hipGetLastError());
 }
 
@@ -916,19 +889,10 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
   if (((uintptr_t)lat->arc_src | (uintptr_t)lat->arc_dst | (uintptr_t)lat->arc_label) & 15) return NFST_ERR_ARG;
   const int64_t lds = nfst_lds_bytes(lat);
-#define NFST_LAUNCH_FB(W)                                                                               \
-  {                                                                                                     \
-    if ((rc = set_lds(k_forward_backward<W>, lds))) return rc;                                          \
-    hipLaunchKernelGGL(k_forward_backward<W>, dim3(lat->n_lattices), dim3(FbGeom<W>::kThreads),         \
-                       (size_t)lds, (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64,      \
-                       logz32, posterior, grad_theta, (float2 *)beta_me);                               \
-  }
-  switch (lat->sweep_waves) {
-    case 1: NFST_LAUNCH_FB(1) break;
-    case 2: NFST_LAUNCH_FB(2) break;
-    default: NFST_LAUNCH_FB(4) break;
-  }
-#undef NFST_LAUNCH_FB
+  if ((rc = set_lds(k_forward_backward, lds))) return rc;
+  hipLaunchKernelGGL(k_forward_backward, dim3(lat->n_lattices), dim3(kFbThreads), (size_t)lds,
+                     (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64, logz32, posterior,
+                     grad_theta, (float2 *)beta_me);
   return hip_status(hipGetLastError());
 }
 
@@ -938,10 +902,10 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (!best || !paths || !lengths || max_len <= 0) return NFST_ERR_ARG;
-  const int64_t lds = (int64_t)lat->max_rows * 8 + (int64_t)lat->vocab * 4;
+  const int64_t lds = (int64_t)lat->max_rows * 8;
   if ((rc = set_lds(k_viterbi, lds))) return rc;
-  hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(256), (size_t)lds, (hipStream_t)stream,
-                     *lat, *scores, best, paths, path_arcs, lengths, (int)max_len, (int)pad);
+  hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(64), (size_t)lds, (hipStream_t)stream, *lat,
+                     *scores, best, paths, path_arcs, lengths, (int)max_len, (int)pad);
   return hip_status(hipGetLastError());
 }
 

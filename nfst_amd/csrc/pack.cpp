@@ -22,9 +22,7 @@ namespace {
 
 struct Opts {
   int n_threads = 0;
-  int max_step_words = NFST_MAX_STEP_WORDS;
-  int lanes_policy = 0;
-  int sweep_waves = 4;
+  int slots_per_lane = 0;  // 0 = choose per lattice and direction
 };
 
 struct Lat {
@@ -35,101 +33,77 @@ struct Lat {
   // results
   std::vector<int32_t> row_ptr;  // n_rows + 1, relative
   std::vector<uint32_t> fwd, bwd;
-  std::vector<int32_t> fwd_perm, bwd_perm;  // relative canonical arc ids
-  int fwd_steps = 0, bwd_steps = 0, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
+  std::vector<int32_t> fwd_perm, bwd_perm;  // per tile slot: relative canonical arc id or -1
+  int fwd_tiles = 0, bwd_tiles = 0, fwd_u = 4, bwd_u = 4, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
   int err = NFST_OK;
 };
 
-// Lanes per state (2^kl) for a step of n_states states whose largest degree is
-// maxdeg, run by W waves: minimise the instructions on one wave's critical path,
-//   tiles(kl) * (iters(kl) * c_iter + kl * c_reduce + c_fixed),
-// tiles = ceil(n_states * 2^kl / (64 W)), iters = ceil(maxdeg / 2^kl).
-// lanes_policy 1 ("throughput") instead keeps lanes busy: the smallest kl with
-// iters <= 4.
-int choose_klog(int n_states, int maxdeg, const Opts &o) {
-  auto iters = [&](int kl) { return (maxdeg + (1 << kl) - 1) >> kl; };
-  if (o.lanes_policy == 1) {
-    int kl = 0;
-    while (kl < 6 && iters(kl) > 4) ++kl;
-    return kl;
-  }
-  const int64_t lanes = 64 * (int64_t)o.sweep_waves;
-  int best = 0;
-  int64_t best_cost = -1;
-  for (int kl = 0; kl <= 6; ++kl) {
-    const int64_t tiles = (((int64_t)n_states << kl) + lanes - 1) / lanes;
-    const int it = iters(kl);
-    // the first two arcs of a lane share one rescale; later ones use the online rule
-    const int64_t per_tile = 12 * std::min(it, 2) + 16 * std::max(it - 2, 0) + 3 * kl + (kl > 4 ? 12 * (kl - 4) : 0) + 24;
-    const int64_t cost = tiles * per_tile;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kl; }
-  }
-  return best;
-}
+inline int ceil_log2(int x) { int g = 0; while ((1 << g) < x) ++g; return g; }
 
-// Emits the steps of one level.  states are sorted by degree (desc).  arcs_of(s)
-// gives [begin,end) into `list` (arc ids), other(a) the state stored in the record.
+// One sweep direction as a "tile program" (DESIGN.md section 3).  A tile is one
+// wave-wide unit of work: 64 control words + 64*U arc records (U = slots per lane).
+// A state with d arcs takes 2^g lanes, g = ceil(log2(ceil(d/U))), at a lane offset
+// that is a multiple of 2^g; lane r of the group owns arcs [r*U, r*U+U).  Tiles
+// never mix levels, so every record's operand was produced by an earlier tile.  A
+// state with more than 64*U arcs is cut into pieces; the later pieces carry the
+// "accumulate" flag and follow in later tiles.
+struct Piece { int32_t state; int32_t begin, end; bool accum; };  // arcs [begin,end) of the state's list
+
 template <class ArcsOf, class Other>
-void emit_level(const std::vector<int32_t> &states, const Opts &o, ArcsOf arcs_of, Other other,
+void emit_level(const std::vector<int32_t> &states, int U, uint32_t null_label, ArcsOf arcs_of, Other other,
                 const std::vector<int32_t> &list, const std::vector<int32_t> &label,
-                std::vector<uint32_t> &stream, std::vector<int32_t> &perm, int &n_steps) {
-  const int max_words = std::max(o.max_step_words, 16);
-  const int max_chunk = std::min(max_words - 4, 65535);
-  size_t i = 0, n = states.size();
-  auto put_rec = [&](int32_t a) {
-    stream.push_back((uint32_t)other(a) | ((uint32_t)label[a] << 16));
-    perm.push_back(a);
-  };
-  while (i < n) {
-    int s = states[i];
+                std::vector<uint32_t> *stream, std::vector<int32_t> *perm, int &n_tiles) {
+  const int cap = 64 * U;
+  std::vector<Piece> head, tail;  // full-wave pieces first, the rest after them
+  for (int32_t s : states) {
     auto r = arcs_of(s);
-    int deg = r.second - r.first;
-    if (deg > max_chunk) {
-      // a state too large for one step: partial sums over consecutive steps, the
-      // later ones flagged "accumulate" (bit 20)
-      for (int c = 0; c < deg; c += max_chunk) {
-        int cnt = std::min(max_chunk, deg - c);
-        Opts oo = o;
-        int kl = choose_klog(1, cnt, oo);
-        stream.push_back(1u | ((uint32_t)kl << 16) | (c > 0 ? (1u << 20) : 0u));
-        stream.push_back((uint32_t)cnt);
-        stream.push_back((uint32_t)s | (0u << 16));
-        stream.push_back(0xFFFFu | ((uint32_t)cnt << 16));
-        for (int k = 0; k < cnt; ++k) put_rec(list[r.first + c + k]);
-        ++n_steps;
+    int b = r.first;
+    bool first = true;
+    while (r.second - b > cap) { head.push_back({s, b, b + cap, !first}); b += cap; first = false; }
+    tail.push_back({s, b, r.second, !first});
+  }
+  auto lanes_of = [&](const Piece &p) { return std::max(1, (p.end - p.begin + U - 1) / U); };
+  std::stable_sort(tail.begin(), tail.end(), [&](const Piece &a, const Piece &b) {
+    return ceil_log2(lanes_of(a)) > ceil_log2(lanes_of(b));
+  });
+  head.insert(head.end(), tail.begin(), tail.end());
+  size_t i = 0;
+  const uint32_t null_rec = null_label << 16;
+  while (i < head.size()) {
+    uint32_t ctl[64];
+    std::vector<uint32_t> rec((size_t)64 * U, null_rec);
+    std::vector<int32_t> pm((size_t)64 * U, -1);
+    for (int l = 0; l < 64; ++l) ctl[l] = 0;
+    int lane = 0, gmax = 0;
+    while (i < head.size()) {
+      const Piece &p = head[i];
+      const int g = ceil_log2(lanes_of(p));
+      const int size = 1 << g;
+      if (lane + size > 64) break;
+      gmax = std::max(gmax, g);
+      for (int r = 0; r < size; ++r) {
+        uint32_t c = (uint32_t)p.state | ((uint32_t)g << 16);
+        if (r == 0) c |= (1u << 13) | (p.accum ? (1u << 14) : 0u);
+        ctl[lane + r] = c;
+        for (int j = 0; j < U; ++j) {
+          const int a = p.begin + r * U + j;
+          if (a < p.end) {
+            const int32_t arc = list[a];
+            rec[(size_t)(lane + r) * U + j] = (uint32_t)other(arc) | ((uint32_t)label[arc] << 16);
+            pm[(size_t)(lane + r) * U + j] = arc;
+          }
+        }
       }
+      lane += size;
       ++i;
-      continue;
     }
-    size_t j = i;
-    int words = 3, arcs = 0, maxdeg = 0;
-    while (j < n) {
-      auto rr = arcs_of(states[j]);
-      int d = rr.second - rr.first;
-      if (d > max_chunk) break;
-      if (j > i && (words + 1 + d > max_words || arcs + d > 65535 || (j - i) >= 65535)) break;
-      words += 1 + d;
-      arcs += d;
-      maxdeg = std::max(maxdeg, d);
-      ++j;
+    for (int l = 0; l < 64; ++l) ctl[l] |= (uint32_t)gmax << 20;
+    if (stream) {
+      stream->insert(stream->end(), ctl, ctl + 64);
+      stream->insert(stream->end(), rec.begin(), rec.end());
+      perm->insert(perm->end(), pm.begin(), pm.end());
     }
-    int ns = (int)(j - i);
-    int kl = choose_klog(ns, std::max(maxdeg, 1), o);
-    stream.push_back((uint32_t)ns | ((uint32_t)kl << 16));
-    stream.push_back((uint32_t)arcs);
-    uint32_t off = 0;
-    for (size_t q = i; q < j; ++q) {
-      auto rr = arcs_of(states[q]);
-      stream.push_back((uint32_t)states[q] | (off << 16));
-      off += (uint32_t)(rr.second - rr.first);
-    }
-    stream.push_back(0xFFFFu | (off << 16));
-    for (size_t q = i; q < j; ++q) {
-      auto rr = arcs_of(states[q]);
-      for (int a = rr.first; a < rr.second; ++a) put_rec(list[a]);
-    }
-    ++n_steps;
-    i = j;
+    ++n_tiles;
   }
 }
 
@@ -190,19 +164,37 @@ void schedule(Lat &L, int vocab, const Opts &o) {
   std::vector<std::vector<int32_t>> by_depth(D + 1), by_height(D + 1);
   for (int s = 0; s < n; ++s)
     if (reach[s]) { by_depth[depth[s]].push_back(s); by_height[height[s]].push_back(s); }
-  L.fwd.clear(); L.bwd.clear(); L.fwd_perm.clear(); L.bwd_perm.clear();
-  L.fwd.reserve(n_dp + 2 * n_reach + 4 * (D + 1));
-  L.bwd.reserve(n_dp + 2 * n_reach + 4 * (D + 1));
-  L.fwd_perm.reserve(n_dp); L.bwd_perm.reserve(n_dp);
   for (int t = 1; t <= D; ++t) {
-    auto &sv = by_height[t];
-    std::stable_sort(sv.begin(), sv.end(), [&](int a, int b) { return outdeg[a] > outdeg[b]; });
-    emit_level(sv, o, [&](int s) { return std::make_pair(out_ptr[s], out_ptr[s + 1]); },
-               [&](int a) { return L.dst[a]; }, out_list, L.label, L.bwd, L.bwd_perm, L.bwd_steps);
-    auto &dv = by_depth[t];
-    std::stable_sort(dv.begin(), dv.end(), [&](int a, int b) { return indeg[a] > indeg[b]; });
-    emit_level(dv, o, [&](int s) { return std::make_pair(in_ptr[s], in_ptr[s + 1]); },
-               [&](int a) { return L.src[a]; }, in_list, L.label, L.fwd, L.fwd_perm, L.fwd_steps);
+    std::stable_sort(by_height[t].begin(), by_height[t].end(), [&](int a, int b) { return outdeg[a] > outdeg[b]; });
+    std::stable_sort(by_depth[t].begin(), by_depth[t].end(), [&](int a, int b) { return indeg[a] > indeg[b]; });
+  }
+  auto out_of = [&](int s) { return std::make_pair(out_ptr[s], out_ptr[s + 1]); };
+  auto in_of = [&](int s) { return std::make_pair(in_ptr[s], in_ptr[s + 1]); };
+  auto dst_of = [&](int a) { return L.dst[a]; };
+  auto src_of = [&](int a) { return L.src[a]; };
+  const uint32_t null_label = (uint32_t)vocab;
+  // slots per lane: fewest tiles wins (tiles are the unit of time); among U whose tile
+  // count is within 10 % of the best the smallest wins (bytes, gathers per tile)
+  auto pick_u = [&](bool backward) {
+    if (o.slots_per_lane == 1 || o.slots_per_lane == 2 || o.slots_per_lane == 4) return o.slots_per_lane;
+    int cnt[3] = {0, 0, 0};
+    const int us[3] = {1, 2, 4};
+    for (int q = 0; q < 3; ++q)
+      for (int t = 1; t <= D; ++t) {
+        if (backward) emit_level(by_height[t], us[q], null_label, out_of, dst_of, out_list, L.label, nullptr, nullptr, cnt[q]);
+        else emit_level(by_depth[t], us[q], null_label, in_of, src_of, in_list, L.label, nullptr, nullptr, cnt[q]);
+      }
+    const int best = std::min(cnt[0], std::min(cnt[1], cnt[2]));
+    for (int q = 0; q < 3; ++q)
+      if (cnt[q] * 10 <= best * 11) return us[q];
+    return 4;
+  };
+  L.bwd_u = pick_u(true);
+  L.fwd_u = pick_u(false);
+  L.fwd.clear(); L.bwd.clear(); L.fwd_perm.clear(); L.bwd_perm.clear();
+  for (int t = 1; t <= D; ++t) {
+    emit_level(by_height[t], L.bwd_u, null_label, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, L.bwd_tiles);
+    emit_level(by_depth[t], L.fwd_u, null_label, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, L.fwd_tiles);
   }
 }
 
@@ -222,9 +214,7 @@ Opts read_opts(const nfst_pack_opts *o) {
   Opts r;
   if (o) {
     r.n_threads = o->n_threads;
-    if (o->max_step_words > 0) r.max_step_words = std::min<int>(o->max_step_words, NFST_MAX_STEP_WORDS);
-    r.lanes_policy = o->lanes_policy;
-    if (o->sweep_waves == 1 || o->sweep_waves == 2 || o->sweep_waves == 4) r.sweep_waves = o->sweep_waves;
+    r.slots_per_lane = o->slots_per_lane;
   }
   return r;
 }
@@ -246,33 +236,36 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
     if (lats[b].err != NFST_OK) { if (err_lattice) *err_lattice = b; return lats[b].err; }
   nfst_packed *p = new (std::nothrow) nfst_packed();
   if (!p) return NFST_ERR_NOMEM;
-  int64_t rows = 0, arcs = 0, dp = 0, fw = 0, bw = 0;
-  int max_rows = 0, max_steps = 0;
+  int64_t rows = 0, arcs = 0, dp = 0, fw = 0, bw = 0, fs = 0, bs = 0;
+  int max_rows = 0, max_tiles = 0;
   p->meta.assign((size_t)B * NFST_META_WORDS, 0);
   for (int b = 0; b < B; ++b) {
     Lat &L = lats[b];
     int32_t *m = &p->meta[(size_t)b * NFST_META_WORDS];
     m[NFST_META_ROW_OFF] = (int32_t)rows; m[NFST_META_N_ROWS] = L.n_rows;
     m[NFST_META_ARC_OFF] = (int32_t)arcs; m[NFST_META_N_ARCS] = (int32_t)L.src.size();
-    m[NFST_META_FWD_OFF] = (int32_t)fw; m[NFST_META_FWD_STEPS] = L.fwd_steps;
-    m[NFST_META_BWD_OFF] = (int32_t)bw; m[NFST_META_BWD_STEPS] = L.bwd_steps;
+    m[NFST_META_FWD_OFF] = (int32_t)fw; m[NFST_META_FWD_TILES] = L.fwd_tiles;
+    m[NFST_META_BWD_OFF] = (int32_t)bw; m[NFST_META_BWD_TILES] = L.bwd_tiles;
     m[NFST_META_SINK] = L.sink; m[NFST_META_N_REACH] = L.n_reach; m[NFST_META_DEPTH] = L.depth;
-    m[NFST_META_DP_OFF] = (int32_t)dp; m[NFST_META_N_DP] = L.n_dp;
-    m[NFST_META_FWD_WORDS] = (int32_t)L.fwd.size(); m[NFST_META_BWD_WORDS] = (int32_t)L.bwd.size();
+    m[NFST_META_N_DP] = L.n_dp; m[NFST_META_FWD_U] = L.fwd_u; m[NFST_META_BWD_U] = L.bwd_u;
+    m[NFST_META_FWD_SLOT_OFF] = (int32_t)fs; m[NFST_META_BWD_SLOT_OFF] = (int32_t)bs;
     rows += L.n_rows; arcs += (int64_t)L.src.size(); dp += L.n_dp;
-    // every lattice's stream starts on a 256-byte boundary (LDS-DMA chunks are 16 B per lane)
-    fw += ((int64_t)L.fwd.size() + 63) / 64 * 64; bw += ((int64_t)L.bwd.size() + 63) / 64 * 64;
+    // tile sizes are multiples of 64 words, so every lattice's stream starts on a
+    // 256-byte boundary (LDS-DMA chunks are 16 B per lane)
+    fw += (int64_t)L.fwd.size(); bw += (int64_t)L.bwd.size();
+    fs += (int64_t)L.fwd_perm.size(); bs += (int64_t)L.bwd_perm.size();
     max_rows = std::max(max_rows, L.n_rows);
-    max_steps = std::max(max_steps, std::max(L.fwd_steps, L.bwd_steps));
-    if (arcs > 0x7fffff00ll || fw > 0x7fffff00ll || bw > 0x7fffff00ll || rows > 0x7fffff00ll) {
+    max_tiles = std::max(max_tiles, std::max(L.fwd_tiles, L.bwd_tiles));
+    if (arcs > 0x7fffff00ll || fw > 0x7ffff000ll || bw > 0x7ffff000ll || rows > 0x7fffff00ll ||
+        fs > 0x7fffff00ll || bs > 0x7fffff00ll) {
       delete p; if (err_lattice) *err_lattice = b; return NFST_ERR_LIMIT;
     }
   }
-  // one LDS-DMA chunk (256 words) + a header of slack at the end of each stream: the
-  // last chunk of the last lattice is read whole
+  // slack at the end of each stream: an empty last lattice still owns valid memory
+  const int64_t slack = 512;
   p->row_ptr.resize(rows + B); p->arc_src.resize(arcs); p->arc_dst.resize(arcs); p->arc_label.resize(arcs);
   if (weighted) p->arc_w.resize(arcs);
-  p->fwd.assign(fw + 512, 0); p->bwd.assign(bw + 512, 0); p->fwd_perm.resize(dp); p->bwd_perm.resize(dp);
+  p->fwd.assign(fw + slack, 0); p->bwd.assign(bw + slack, 0); p->fwd_perm.resize(fs); p->bwd_perm.resize(bs);
   parallel_for(B, o.n_threads, [&](int b) {
     Lat &L = lats[b];
     const int32_t *m = &p->meta[(size_t)b * NFST_META_WORDS];
@@ -288,16 +281,16 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
     }
     if (!L.fwd.empty()) std::memcpy(&p->fwd[m[NFST_META_FWD_OFF]], L.fwd.data(), L.fwd.size() * 4);
     if (!L.bwd.empty()) std::memcpy(&p->bwd[m[NFST_META_BWD_OFF]], L.bwd.data(), L.bwd.size() * 4);
-    int32_t d0 = m[NFST_META_DP_OFF];
-    for (int i = 0; i < L.n_dp; ++i) { p->fwd_perm[d0 + i] = a0 + L.fwd_perm[i]; p->bwd_perm[d0 + i] = a0 + L.bwd_perm[i]; }
+    int32_t *fp = L.fwd_perm.empty() ? nullptr : &p->fwd_perm[m[NFST_META_FWD_SLOT_OFF]];
+    int32_t *bp = L.bwd_perm.empty() ? nullptr : &p->bwd_perm[m[NFST_META_BWD_SLOT_OFF]];
+    for (size_t i = 0; i < L.fwd_perm.size(); ++i) fp[i] = L.fwd_perm[i] < 0 ? -1 : a0 + L.fwd_perm[i];
+    for (size_t i = 0; i < L.bwd_perm.size(); ++i) bp[i] = L.bwd_perm[i] < 0 ? -1 : a0 + L.bwd_perm[i];
     std::vector<int32_t>().swap(L.src); std::vector<uint32_t>().swap(L.fwd); std::vector<uint32_t>().swap(L.bwd);
   });
   nfst_batch &v = p->view;
-  v.n_lattices = B; v.vocab = vocab; v.max_rows = max_rows; v.max_steps = max_steps;
-  v.weighted = weighted ? 1 : 0; v.total_rows = rows; v.total_arcs = arcs; v.total_dp_arcs = dp;
-  v.fwd_words = fw + 512; v.bwd_words = bw + 512;
-  v.max_step_words = o.max_step_words;
-  v.sweep_waves = o.sweep_waves;
+  v.n_lattices = B; v.vocab = vocab; v.max_rows = max_rows; v.max_tiles = max_tiles;
+  v.weighted = weighted ? 1 : 0; v.reserved0 = 0; v.total_rows = rows; v.total_arcs = arcs; v.total_dp_arcs = dp;
+  v.fwd_words = fw + slack; v.bwd_words = bw + slack; v.fwd_slots = fs; v.bwd_slots = bs;
   v.meta = p->meta.data(); v.row_ptr = p->row_ptr.data(); v.arc_src = p->arc_src.data();
   v.arc_dst = p->arc_dst.data(); v.arc_label = p->arc_label.data();
   v.arc_w = weighted ? p->arc_w.data() : nullptr;
@@ -421,7 +414,7 @@ const char *nfst_strerror(int code) {
     case NFST_ERR_CYCLE: return "lattice is not acyclic";
     case NFST_ERR_SINK: return "lattice must have exactly one final (sink) state";
     case NFST_ERR_DETERMINISM: return "two arcs leave one state with the same label";
-    case NFST_ERR_LIMIT: return "lattice exceeds engine limits (rows <= 8192, vocab <= 32768)";
+    case NFST_ERR_LIMIT: return "lattice exceeds engine limits (rows <= 8192, vocab <= 32767)";
     case NFST_ERR_HIP: return "HIP runtime error";
     case NFST_ERR_NOMEM: return "out of memory";
     case NFST_ERR_LENGTH: return "ran out of length budget";

@@ -46,8 +46,8 @@ class LatticeBatch:
 
     # ---------------------------------------------------------------- construction
     @staticmethod
-    def _opts(n_threads=0, max_step_words=0, lanes_policy=0, sweep_waves=0):
-        return _lib.PackOpts(int(n_threads), int(max_step_words), int(lanes_policy), int(sweep_waves))
+    def _opts(n_threads=0, slots_per_lane=0):
+        return _lib.PackOpts(int(n_threads), int(slots_per_lane), 0, 0)
 
     @classmethod
     def _from_handle(cls, handle, device) -> "LatticeBatch":
@@ -64,12 +64,12 @@ class LatticeBatch:
                 "arc_w": _view(v.arc_w, v.total_arcs, C.c_float, np.float32) if v.weighted else None,
                 "fwd_stream": _view(v.fwd_stream, v.fwd_words, C.c_int32, np.int32),
                 "bwd_stream": _view(v.bwd_stream, v.bwd_words, C.c_int32, np.int32),
-                "fwd_perm": _view(v.fwd_perm, v.total_dp_arcs, C.c_int32, np.int32),
-                "bwd_perm": _view(v.bwd_perm, v.total_dp_arcs, C.c_int32, np.int32),
+                "fwd_perm": _view(v.fwd_perm, v.fwd_slots, C.c_int32, np.int32),
+                "bwd_perm": _view(v.bwd_perm, v.bwd_slots, C.c_int32, np.int32),
             }
-            header = {k: int(getattr(v, k)) for k in ("n_lattices", "vocab", "max_rows", "max_steps", "weighted",
-                                                      "max_step_words", "sweep_waves", "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
-                                                      "bwd_words")}
+            header = {k: int(getattr(v, k)) for k in ("n_lattices", "vocab", "max_rows", "max_tiles", "weighted", "reserved0",
+                                                      "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
+                                                      "bwd_words", "fwd_slots", "bwd_slots")}
         finally:
             lib.nfst_packed_free(handle)
         tensors = {k: (None if a is None else torch.from_numpy(a)) for k, a in arrs.items()}

@@ -20,7 +20,7 @@ namespace {
 #define STAMP(slot) do { if (dbg_on && t >= 20 && t < 52) { unsigned long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory"); if (lane == 0) g_dbg[dbg_base + (t-20)*8 + (slot)] = c_; } } while(0)
 
 constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
-constexpr int kSweepWaves = 4;          // waves per sweep direction
+constexpr int kViterbiWaves = 4;        // waves of the Viterbi kernel
 constexpr float kNegInf = -__builtin_huge_valf();
 
 struct ME {
@@ -103,61 +103,86 @@ struct Extra {
 };
 
 // ---------------------------------------------------------------- LDS ring (LDS-DMA)
-// A sweep consumes its stream strictly front to back, and the stream does not
-// depend on the DP values, so it is prefetched arbitrarily far ahead: each of the
-// sweep's 4 waves copies every 4th 1-KiB chunk straight into a 16 KiB LDS ring
-// with global_load_lds_dwordx4 (no VGPR staging).  Chunk c lives in slot c % 16.
-// Invariants (one step is at most NFST_MAX_STEP_WORDS = 1024 words):
-//   * before the barrier that ends step t-1 every wave has waited (counted vmcnt)
-//     for its chunks below word off_t + 1026: step t and the header of step t+1
-//     are then visible to all waves;
-//   * a slot is refilled only after a barrier that follows the last step reading it.
+// A sweep consumes its stream strictly front to back and the stream does not
+// depend on the DP values, so it is prefetched far ahead: the sweep's W waves copy
+// 1-KiB chunks straight into a 16 KiB LDS ring with global_load_lds_dwordx4 (no
+// VGPR staging).  The ring is 8 blocks of 512 words (2 chunks each); chunk c is
+// issued by wave c % W and lives in slot c % 16.  A step is at most
+// NFST_MAX_STEP_WORDS = 512 words, so while the read offset is in block b a step
+// (plus the next step's 2-word header) touches blocks b .. b+2 only.  Protocol, run
+// (plus the static data of the following step and the header after that, which the
+// software pipeline reads early) touches blocks b .. b+3 only.  Protocol, run by
+// every wave when the offset enters block b ("crossing", at the top of a step, i.e.
+// after the barrier that ended the previous step):
+//   1. blocks < b are dead: issue the chunks this wave owns of block b+7 into them;
+//   2. counted wait: all of this wave's chunks of blocks <= b+4 have landed
+//      (blocks b+5 .. b+7 may stay in flight -- the constant vmcnt below);
+//   3. the barrier that ends this step publishes block b+4, one crossing before
+//      any wave can read it.
+// The prologue issues blocks 0..7 and waits for blocks 0..4 with the same constant.
 constexpr int kRingWords = 4096;
 constexpr int kRingMask = kRingWords - 1;
 constexpr int kChunkWords = 256;
-constexpr int kSlots = kRingWords / kChunkWords;
-constexpr int kLookahead = NFST_MAX_STEP_WORDS + 2;
+constexpr int kBlockShift = 9;  // 512-word blocks
 
+template <int W>
 struct Ring {
-  uint32_t *lds;        // ring base in LDS
-  const uint32_t *g;    // this lattice's stream (256-byte aligned)
+  uint32_t *lds;      // ring base in LDS
+  const uint32_t *g;  // this lattice's stream (256-byte aligned)
   int total_chunks;
-  int next_c;           // next chunk this wave issues: w, w+4, ...
-  int issued;           // chunks issued by this wave
-  int w;
+  int blk;            // block holding the current read offset
+  int w;              // this wave's index within the sweep
 };
 
-__device__ __forceinline__ void ring_init(Ring &r, uint32_t *lds, const uint32_t *g, int words, int w) {
-  r.lds = lds; r.g = g; r.total_chunks = (words + kChunkWords - 1) / kChunkWords;
-  r.next_c = w; r.issued = 0; r.w = w;
-}
-
-// issue every chunk whose slot no longer holds words >= off (the first word still needed)
-__device__ __forceinline__ void ring_refill(Ring &r, int off, int lane) {
-  while (r.next_c < r.total_chunks && (r.next_c - kSlots + 1) * kChunkWords <= off) {
-    const uint32_t *src = r.g + (size_t)r.next_c * kChunkWords + lane * 4;
-    uint32_t *dst = r.lds + (r.next_c & (kSlots - 1)) * kChunkWords;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    r.next_c += kSweepWaves;
-    r.issued += 1;
+template <int W>
+__device__ __forceinline__ void ring_issue_block(const Ring<W> &r, int block, int lane) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = 2 * block + q;
+    if ((c % W) != r.w) continue;
+    uint32_t *dst = r.lds + (c & 15) * kChunkWords;
+    if (c < r.total_chunks) {
+      const uint32_t *src = r.g + (size_t)c * kChunkWords + lane * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    } else {
+      // past the end of the stream: a 4-byte-per-lane placeholder load into the (dead)
+      // slot keeps the wave's vmcnt sequence identical, so the constant waits stay exact
+      const uint32_t *src = r.g + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+    }
   }
 }
 
-// wait until this wave's chunks covering words < need have landed
-__device__ __forceinline__ void ring_wait(const Ring &r, int need) {
-  int need_c = (need - 1) >> 8;
-  if (need_c > r.total_chunks - 1) need_c = r.total_chunks - 1;
-  const int n_need = need_c >= r.w ? ((need_c - r.w) >> 2) + 1 : 0;
-  const int allow = r.issued - n_need;  // loads that may stay in flight
-  if (allow <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (allow == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+template <int W>
+__device__ __forceinline__ void ring_wait() {
+  // chunks a wave may leave in flight: its share of blocks b+5 .. b+7
+  if (W == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (W == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+}
+
+template <int W>
+__device__ __forceinline__ void ring_start(Ring<W> &r, uint32_t *lds, const uint32_t *g, int words, int w,
+                                           int lane) {
+  r.lds = lds; r.g = g; r.total_chunks = (words + kChunkWords - 1) / kChunkWords; r.blk = 0; r.w = w;
+  for (int b = 0; b < 8; ++b) ring_issue_block(r, b, lane);
+  ring_wait<W>();
+}
+
+template <int W>
+__device__ __forceinline__ void ring_advance(Ring<W> &r, int off, int lane) {
+  const int nb = off >> kBlockShift;
+  if (nb != r.blk) {  // a step is at most one block long: nb == blk + 1
+    r.blk = nb;
+    ring_issue_block(r, nb + 7, lane);
+    ring_wait<W>();
+  }
 }
 
 // workgroup barrier that does not drain the LDS-DMA queue (a __syncthreads() would
-// wait vmcnt(0)): LDS writes of this wave are complete, then s_barrier.
+// wait vmcnt(0)): this wave's LDS writes are complete, then s_barrier.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -167,123 +192,202 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
-
-// (M, E) += partner's (M, E); PARTNER is a DPP control or a shuffle distance
-#define NFST_COMBINE_DPP(CTRL)                                            \
-  {                                                                       \
-    const float Mo = __int_as_float(dpp_i<CTRL>(__float_as_int(M)));      \
-    const int Eo = dpp_i<CTRL>(E);                                        \
-    const int En = max(E, Eo);                                            \
-    M = ldexpf(M, E - En) + ldexpf(Mo, Eo - En);                          \
-    E = En;                                                               \
-  }
-#define NFST_COMBINE_XOR(D)                                               \
-  {                                                                       \
-    const float Mo = __shfl_xor(M, D);                                    \
-    const int Eo = __shfl_xor(E, D);                                      \
-    const int En = max(E, Eo);                                            \
-    M = ldexpf(M, E - En) + ldexpf(Mo, Eo - En);                          \
-    E = En;                                                               \
-  }
-
-// all-reduce of (M, E) over groups of 2^kl neighbouring lanes: quad permutes, then
-// half-row / row mirrors (DPP, no LDS traffic), then cross-row shuffles
-__device__ __forceinline__ void group_reduce(float &M, int &E, int kl) {
-  if (kl >= 1) NFST_COMBINE_DPP(0xB1)   // quad_perm [1,0,3,2]
-  if (kl >= 2) NFST_COMBINE_DPP(0x4E)   // quad_perm [2,3,0,1]
-  if (kl >= 3) NFST_COMBINE_DPP(0x141)  // row_half_mirror
-  if (kl >= 4) NFST_COMBINE_DPP(0x140)  // row_mirror
-  if (kl >= 5) NFST_COMBINE_XOR(16)
-  if (kl >= 6) NFST_COMBINE_XOR(32)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// One sum-product sweep over one direction's stream, run by kSweepWaves waves
-// (index w) of the workgroup; every wave of the workgroup calls lds_barrier()
-// n_barriers times in total.
-__device__ __forceinline__ void ring_sweep(Ring &rg, int my_steps, int n_barriers, float2 *val,
-                                           const float2 *th, const Extra ex,
+// All-reduce of an (M, E) partial sum over groups of 2^KL neighbouring lanes:
+// max of the exponents, one rescale, then the sum.  Quad permutes and half-row /
+// row mirrors are DPP modifiers (no LDS traffic); 32- and 64-lane groups finish with
+// shuffles.  Every lane of a group ends with bitwise the same (M, E).
+template <int KL>
+__device__ __forceinline__ void group_reduce(float &M, int &E) {
+  int Em = E;
+  if (KL >= 1) Em = max(Em, dpp_i<0xB1>(Em));   // quad_perm [1,0,3,2]
+  if (KL >= 2) Em = max(Em, dpp_i<0x4E>(Em));   // quad_perm [2,3,0,1]
+  if (KL >= 3) Em = max(Em, dpp_i<0x141>(Em));  // row_half_mirror
+  if (KL >= 4) Em = max(Em, dpp_i<0x140>(Em));  // row_mirror
+  if (KL >= 5) Em = max(Em, __shfl_xor(Em, 16));
+  if (KL >= 6) Em = max(Em, __shfl_xor(Em, 32));
+  if (KL >= 1) {
+    M = ldexpf(M, E - Em);
+    E = Em;
+  }
+  if (KL >= 1) M += dpp_f<0xB1>(M);
+  if (KL >= 2) M += dpp_f<0x4E>(M);
+  if (KL >= 3) M += dpp_f<0x141>(M);
+  if (KL >= 4) M += dpp_f<0x140>(M);
+  if (KL >= 5) M += __shfl_xor(M, 16);
+  if (KL >= 6) M += __shfl_xor(M, 32);
+}
+
+// ---------------------------------------------------------------- the sweep proper
+constexpr int kUnroll = 4;  // arcs per lane handled by the straight-line path
+
+// scalar description of one step (wave-uniform, lives in SGPRs)
+struct StepHdr {
+  int off, ns, kl, na, st, rec, next_off, arc_base;
+  bool accum;
+};
+__device__ __forceinline__ StepHdr make_hdr(int off, uint32_t h0, uint32_t na, int arc_base) {
+  StepHdr h;
+  h.off = off; h.ns = (int)(h0 & 0xffffu); h.kl = (int)((h0 >> 16) & 0xfu); h.na = (int)na;
+  h.accum = ((h0 >> 20) & 1u) != 0;
+  h.st = off + 2; h.rec = h.st + h.ns + 1; h.next_off = h.rec + h.na; h.arc_base = arc_base;
+  return h;
+}
+
+// per-lane static data of one tile: the lane's state, its arc range and its first
+// kUnroll arc records.  Nothing here depends on DP values, so a tile's TileRegs are
+// fetched from the ring while the previous tile is being computed.
+struct TileRegs {
+  uint32_t rc[kUnroll];
+  uint32_t sid;
+  int a0, a1;  // this lane's arcs: a0, a0 + k, ... < a1 (both 0 for an idle lane)
+};
+
+__device__ __forceinline__ void tile_fetch(const uint32_t *ring, const StepHdr &h, int base, int lane,
+                                           TileRegs &tr) {
+  const int k = 1 << h.kl;
+  const int i = base + (lane >> h.kl);
+  const int r = lane & (k - 1);
+  const uint32_t w0 = ring[(h.st + i) & kRingMask], w1 = ring[(h.st + i + 1) & kRingMask];
+  const bool act = i < h.ns;
+  tr.sid = w0 & 0xffffu;
+  tr.a0 = act ? (int)(w0 >> 16) + r : 0;
+  tr.a1 = act ? (int)(w1 >> 16) : 0;
+#pragma unroll
+  for (int j = 0; j < kUnroll; ++j) {
+    const int a = tr.a0 + j * k;
+    const uint32_t v = ring[(h.rec + a) & kRingMask];  // always a valid LDS address
+    tr.rc[j] = (a < tr.a1) ? v : 0u;
+  }
+}
+
+// One sum-product sweep over one direction's stream, run by W waves (index w) of the
+// workgroup.  With W > 1 the waves meet at one barrier per step and every wave of the
+// workgroup must call lds_barrier() exactly n_barriers + 1 times; with W == 1 a sweep
+// is a single wave, its LDS accesses are ordered, and there is no barrier at all.
+// Software pipeline, per tile: gathers of this tile (theta, alpha/beta) are issued
+// first, then the static reads of the wave's next tile; the sum, the cross-lane
+// reduce and the LDS write of this tile run while those are in flight.
+template <int W>
+__device__ __forceinline__ void ring_sweep(const uint32_t *g, int words, uint32_t *ring_lds, int my_steps,
+                                           int n_barriers, float2 *val, const float2 *th, const Extra ex,
                                            const int32_t *__restrict__ perm, int w, int lane) {
-  const uint32_t *ring = rg.lds;
+  Ring<W> rg;
+  ring_start(rg, ring_lds, g, words, w, lane);
+  if (W > 1) lds_barrier();
+  const uint32_t *ring = ring_lds;
   const bool has_extra = ex.any();
   const bool dbg_on = (blockIdx.x == 7);
   const int dbg_base = (int)(threadIdx.x >> 6) * 512;
-  ring_refill(rg, 0, lane);
-  ring_wait(rg, kLookahead);
-  lds_barrier();
-  int off = 0, arc_base = 0;
-  uint32_t h0 = 0, na_u = 0;
-  if (my_steps > 0) {
-    h0 = __builtin_amdgcn_readfirstlane(ring[0]);
-    na_u = __builtin_amdgcn_readfirstlane(ring[1]);
+  StepHdr H0 = make_hdr(0, 0, 0, 0), H1 = H0;
+  if (my_steps > 0)
+    H0 = make_hdr(0, __builtin_amdgcn_readfirstlane(ring[0]), __builtin_amdgcn_readfirstlane(ring[1]), 0);
+  if (my_steps > 1)
+    H1 = make_hdr(H0.next_off, __builtin_amdgcn_readfirstlane(ring[H0.next_off & kRingMask]),
+                  __builtin_amdgcn_readfirstlane(ring[(H0.next_off + 1) & kRingMask]), H0.na);
+  TileRegs cur;
+  bool have = false;
+  if (my_steps > 0 && w * (64 >> H0.kl) < H0.ns) {
+    tile_fetch(ring, H0, w * (64 >> H0.kl), lane, cur);
+    have = true;
   }
   for (int t = 0; t < n_barriers; ++t) {
     if (t < my_steps) {
       STAMP(0);
-      const int na = (int)na_u;
-      const int ns = (int)(h0 & 0xffffu);
-      const int kl = (int)((h0 >> 16) & 0xfu);
-      const bool accum = ((h0 >> 20) & 1u) != 0;
-      const int st = off + 2;
-      const int rec = st + ns + 1;
-      const int next_off = rec + na;
-      ring_refill(rg, off, lane);
-      // header of the next step (static data, already landed)
-      uint32_t nh0 = 0, nna = 0;
-      if (t + 1 < my_steps) {
-        nh0 = ring[next_off & kRingMask];
-        nna = ring[(next_off + 1) & kRingMask];
-      }
-      STAMP(1);
-      const int spw = 64 >> kl;
-      const int k = 1 << kl;
-      for (int base = w * spw; base < ns; base += kSweepWaves * spw) {
-        const int i = base + (lane >> kl);
-        const int r = lane & (k - 1);
-        float M = 0.0f;
-        int E = kEZero;
-        uint32_t sid = 0;
-        if (i < ns) {
-          const uint32_t w0 = ring[(st + i) & kRingMask], w1 = ring[(st + i + 1) & kRingMask];
-          sid = w0 & 0xffffu;
-          const int a0 = (int)(w0 >> 16), a1 = (int)(w1 >> 16);
-          for (int a = a0 + r; a < a1; a += k) {
-            const uint32_t rc = ring[(rec + a) & kRingMask];
-            const float2 tw = th[rc >> 16];
-            const float2 v = val[rc & 0xffffu];
-            float mw = tw.x;
-            int ew = __float_as_int(tw.y);
+      ring_advance(rg, H0.off, lane);
+      // header of step t+2 (static data that has already landed)
+      const bool v1 = t + 1 < my_steps, v2 = t + 2 < my_steps;
+      const uint32_t f0 = ring[H1.next_off & kRingMask], f1 = ring[(H1.next_off + 1) & kRingMask];
+      const int spw = 64 >> H0.kl;
+      const int k = 1 << H0.kl;
+      for (int base = w * spw; base < H0.ns; base += W * spw) {
+        if (!have) tile_fetch(ring, H0, base, lane, cur);
+        STAMP(1);
+        // --- A: gathers of this tile
+        float2 tw[kUnroll], vv[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+          tw[j] = th[cur.rc[j] >> 16];
+          vv[j] = val[cur.rc[j] & 0xffffu];
+        }
+        // --- B: static data of this wave's next tile (same step, else the next step)
+        const int nbase = base + W * spw;
+        const bool same = nbase < H0.ns;
+        const int nb1 = w * (64 >> H1.kl);
+        const bool hv = same || (v1 && nb1 < H1.ns);
+        const StepHdr Hn = same ? H0 : (hv ? H1 : H0);
+        const int nb = same ? nbase : (hv ? nb1 : base);
+        TileRegs nxt;
+        tile_fetch(ring, Hn, nb, lane, nxt);
+        STAMP(2);
+        // --- C: this tile's sum with one shared exponent
+        float mt[kUnroll];
+        int et[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+          const bool ok = cur.a0 + j * k < cur.a1;
+          float mw = tw[j].x;
+          int ew = __float_as_int(tw[j].y);
+          if (has_extra) {
+            const int a = ok ? cur.a0 + j * k : 0;
+            ME x = exp_split(ex.at(perm[H0.arc_base + a]));
+            mw *= x.m;
+            ew += x.e;
+          }
+          mt[j] = ok ? mw * vv[j].x : 0.0f;
+          et[j] = ok ? ew + __float_as_int(vv[j].y) : kEZero;
+        }
+        int E = max(max(et[0], et[1]), max(et[2], et[3]));
+        float M = (ldexpf(mt[0], et[0] - E) + ldexpf(mt[1], et[1] - E)) +
+                  (ldexpf(mt[2], et[2] - E) + ldexpf(mt[3], et[3] - E));
+        STAMP(3);
+        // --- E: lanes with more than kUnroll arcs (the packer avoids this when it can)
+        if (__any(cur.a0 + kUnroll * k < cur.a1)) {
+          for (int a = cur.a0 + kUnroll * k; a < cur.a1; a += k) {
+            const uint32_t rc = ring[(H0.rec + a) & kRingMask];
+            const float2 t2 = th[rc >> 16], v2f = val[rc & 0xffffu];
+            float mw = t2.x;
+            int ew = __float_as_int(t2.y);
             if (has_extra) {
-              ME x = exp_split(ex.at(perm[arc_base + a]));
+              ME x = exp_split(ex.at(perm[H0.arc_base + a]));
               mw *= x.m;
               ew += x.e;
             }
-            me_acc(M, E, mw * v.x, ew + __float_as_int(v.y));
+            me_acc(M, E, mw * v2f.x, ew + __float_as_int(v2f.y));
           }
         }
-        STAMP(2);
-        group_reduce(M, E, kl);
-        STAMP(3);
-        if (i < ns && r == 0) {
-          if (accum) {
-            const float2 old = val[sid];
-            const int Eo = __float_as_int(old.y);
-            const int En = max(E, Eo);
-            M = ldexpf(M, E - En) + ldexpf(old.x, Eo - En);
-            E = En;
-          }
-          val[sid] = me_pack(M, E);
+        STAMP(4);
+        // --- F: reduce over the state's lanes, normalise, store
+        switch (H0.kl) {
+          case 0: group_reduce<0>(M, E); break;
+          case 1: group_reduce<1>(M, E); break;
+          case 2: group_reduce<2>(M, E); break;
+          case 3: group_reduce<3>(M, E); break;
+          case 4: group_reduce<4>(M, E); break;
+          case 5: group_reduce<5>(M, E); break;
+          default: group_reduce<6>(M, E); break;
         }
+        if ((lane & (k - 1)) == 0 && base + (lane >> H0.kl) < H0.ns) {
+          if (H0.accum) {
+            const float2 old = val[cur.sid];
+            me_acc(M, E, old.x, __float_as_int(old.y));
+          }
+          val[cur.sid] = me_pack(M, E);
+        }
+        STAMP(5);
+        cur = nxt;
+        have = hv;
       }
-      STAMP(4);
-      off = next_off;
-      arc_base += na;
-      h0 = __builtin_amdgcn_readfirstlane(nh0);
-      na_u = __builtin_amdgcn_readfirstlane(nna);
-      // step t+1 and the header of step t+2 must be visible after the barrier
-      if (t + 1 < my_steps) ring_wait(rg, off + kLookahead);
-      STAMP(5);
+      // rotate the headers
+      H0 = H1;
+      if (v2) H1 = make_hdr(H1.next_off, __builtin_amdgcn_readfirstlane(f0), __builtin_amdgcn_readfirstlane(f1),
+                            H1.arc_base + H1.na);
     }
-    lds_barrier();
+    if (W > 1) lds_barrier();
     STAMP(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight
@@ -299,48 +403,72 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
 }
 
 // ------------------------------------------------------------------ backward only
-// 256 threads: 4 waves sweep the by-source stream from the sink.
-__global__ __launch_bounds__(256) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
-                                                  double *logz64, float *logz32, float2 *beta_me) {
+// W waves sweep the by-source stream from the sink (block = max(W, 2) * 64 threads...
+// exactly W * 64 threads).
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
+                                                     double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NT = W * 64;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
   const int rows2 = (lat.max_rows + 1) & ~1;
   float2 *beta = lds;
   float2 *th = lds + rows2;
   uint32_t *ring_lds = (uint32_t *)(th + ((lat.vocab + 1) & ~1));
-  for (int i = tid; i < m.n_rows; i += 256) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
-  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, 256);
+  for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
   if (tid == 0) beta[m.sink] = make_float2(0.5f, __int_as_float(1));
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int w = __builtin_amdgcn_readfirstlane(wave);
-  Ring rg;
-  ring_init(rg, ring_lds, lat.bwd_stream + m.bwd_off, m.bwd_words, w);
-  ring_sweep(rg, m.bwd_steps, m.bwd_steps, beta, th, ex, lat.bwd_perm + m.dp_off, w, lane);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, m.bwd_steps, beta, th, ex,
+                lat.bwd_perm + m.dp_off, w, lane);
+  __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
     if (logz64) logz64[b] = z;
     if (logz32) logz32[b] = (float)z;
   }
-  for (int i = tid; i < m.n_rows; i += 256) {
+  for (int i = tid; i < m.n_rows; i += NT) {
     if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
     if (beta_me) beta_me[m.row_off + i] = beta[i];
   }
 }
 
 // ------------------------------------------------------------------ forward-backward
-// 512 threads: waves 0-3 run the beta sweep, waves 4-7 the alpha sweep, level by
-// level and concurrently; then all waves stream the canonical arcs once more for
-// the posteriors.
-__global__ __launch_bounds__(512) void k_forward_backward(nfst_batch lat, nfst_scores sc,
-                                                          float *logalpha, float *logbeta,
-                                                          double *logz64, float *logz32,
-                                                          float *posterior, float *grad_theta,
-                                                          float2 *beta_me) {
+// Waves [0, W) run the beta sweep and waves [W, 2W) the alpha sweep, concurrently;
+// then every wave of the block streams the canonical arcs once for the posteriors.
+// W = 1: 256-thread block, the two sweeps are single waves that never synchronise
+// (the other two waves wait at the barrier before the posterior pass).
+template <int W>
+struct FbGeom {
+  static constexpr int kThreads = (2 * W * 64 < 256) ? 256 : 2 * W * 64;
+};
+
+__device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv, const float2 tw, float rz,
+                                               int ez, bool has_extra, const Extra &ex, int a) {
+  float mw = tw.x;
+  int ew = __float_as_int(tw.y);
+  if (has_extra) {
+    ME x = exp_split(ex.at(a));
+    mw *= x.m;
+    ew += x.e;
+  }
+  const float mm = (av.x * mw) * (bv.x * rz);
+  const int ee = __float_as_int(av.y) + ew + __float_as_int(bv.y) - ez;
+  return ldexpf(mm, max(ee, -300));
+}
+
+template <int W>
+__global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
+    nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
+    double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
+    float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NT = FbGeom<W>::kThreads;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
   const int rows2 = (lat.max_rows + 1) & ~1;
   const int v4 = (lat.vocab + 3) & ~3;
@@ -349,12 +477,12 @@ __global__ __launch_bounds__(512) void k_forward_backward(nfst_batch lat, nfst_s
   float2 *th = lds + 2 * rows2;
   float *gth = (float *)(th + v4);             // [V] label histogram (only if grad_theta)
   uint32_t *ring_lds = (uint32_t *)(gth + v4);  // two 16 KiB rings: beta stream, alpha stream
-  for (int i = tid; i < m.n_rows; i += 512) {
+  for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   }
-  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, 512);
-  if (grad_theta) for (int l = tid; l < lat.vocab; l += 512) gth[l] = 0.0f;
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
+  if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   __syncthreads();
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
@@ -362,17 +490,14 @@ __global__ __launch_bounds__(512) void k_forward_backward(nfst_batch lat, nfst_s
   }
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const bool fwd = wv >= kSweepWaves;
-  const int w = fwd ? wv - kSweepWaves : wv;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int all_steps = max(m.fwd_steps, m.bwd_steps);
-  Ring rg;
-  if (fwd) {
-    ring_init(rg, ring_lds + kRingWords, lat.fwd_stream + m.fwd_off, m.fwd_words, w);
-    ring_sweep(rg, m.fwd_steps, all_steps, alpha, th, ex, lat.fwd_perm + m.dp_off, w, lane);
-  } else {
-    ring_init(rg, ring_lds, lat.bwd_stream + m.bwd_off, m.bwd_words, w);
-    ring_sweep(rg, m.bwd_steps, all_steps, beta, th, ex, lat.bwd_perm + m.dp_off, w, lane);
+  if (wv < W) {
+    ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, all_steps, beta, th, ex,
+                  lat.bwd_perm + m.dp_off, wv, lane);
+  } else if (wv < 2 * W) {
+    ring_sweep<W>(lat.fwd_stream + m.fwd_off, m.fwd_words, ring_lds + kRingWords, m.fwd_steps, all_steps,
+                  alpha, th, ex, lat.fwd_perm + m.dp_off, wv - W, lane);
   }
   __syncthreads();
   const float2 zme = beta[0];
@@ -381,7 +506,7 @@ __global__ __launch_bounds__(512) void k_forward_backward(nfst_batch lat, nfst_s
     if (logz64) logz64[b] = z;
     if (logz32) logz32[b] = (float)z;
   }
-  for (int i = tid; i < m.n_rows; i += 512) {
+  for (int i = tid; i < m.n_rows; i += NT) {
     if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
     if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
     if (beta_me) beta_me[m.row_off + i] = beta[i];
@@ -390,29 +515,38 @@ __global__ __launch_bounds__(512) void k_forward_backward(nfst_batch lat, nfst_s
     const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
     const int ez = __float_as_int(zme.y);
     const bool has_extra = ex.any();
-    for (int a = m.arc_off + tid; a < m.arc_off + m.n_arcs; a += 512) {
-      const int s = lat.arc_src[a], d = lat.arc_dst[a], l = lat.arc_label[a];
-      float p = 0.0f;
-      if (s != d) {
-        const float2 av = alpha[s], bv = beta[d], tw = th[l];
-        float mw = tw.x;
-        int ew = __float_as_int(tw.y);
-        if (has_extra) {
-          ME x = exp_split(ex.at(a));
-          mw *= x.m;
-          ew += x.e;
-        }
-        const float mm = (av.x * mw) * (bv.x * rz);
-        const int ee = __float_as_int(av.y) + ew + __float_as_int(bv.y) - ez;
-        p = ldexpf(mm, max(ee, -300));
+    const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
+    // 4 arcs per lane and iteration with 16-byte loads/stores on the aligned interior
+    const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
+    for (int a = v_begin + tid * 4; a < v_end; a += NT * 4) {
+      const int4 s4 = *reinterpret_cast<const int4 *>(lat.arc_src + a);
+      const int4 d4 = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
+      const int4 l4 = *reinterpret_cast<const int4 *>(lat.arc_label + a);
+      const int ss[4] = {s4.x, s4.y, s4.z, s4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w},
+                ll[4] = {l4.x, l4.y, l4.z, l4.w};
+      float pp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pp[q] = (ss[q] != dd[q]) ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
+                                 : 0.0f;
+        if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
       }
+      if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    }
+    // unaligned head and tail (at most 3 arcs each)
+    const int n_head = min(v_begin, a_end) - a_begin;
+    const int n_tail = (v_end >= v_begin) ? a_end - v_end : 0;
+    if (tid < n_head + n_tail) {
+      const int a = tid < n_head ? a_begin + tid : v_end + (tid - n_head);
+      const int s = lat.arc_src[a], d = lat.arc_dst[a], l = lat.arc_label[a];
+      const float p = (s != d) ? arc_posterior(alpha[s], beta[d], th[l], rz, ez, has_extra, ex, a) : 0.0f;
       if (posterior) posterior[a] = p;
       if (grad_theta && p > 0.0f) atomicAdd(&gth[l], p);
     }
     if (grad_theta) {
       __syncthreads();
       float *g = grad_theta + (size_t)b * lat.vocab;
-      for (int l = tid; l < lat.vocab; l += 512) g[l] = gth[l];
+      for (int l = tid; l < lat.vocab; l += NT) g[l] = gth[l];
     }
   }
 }
@@ -447,7 +581,7 @@ __global__ __launch_bounds__(256) void k_viterbi(nfst_batch lat, nfst_scores sc,
     const bool accum = ((h0 >> 20) & 1u) != 0;
     const uint32_t *st = step + 2, *rec = st + ns + 1;
     const int spw = 64 >> kl, k = 1 << kl;
-    for (int base = wave * spw; base < ns; base += kSweepWaves * spw) {
+    for (int base = wave * spw; base < ns; base += kViterbiWaves * spw) {
       const int i = base + (lane >> kl), r = lane & (k - 1);
       float bv = kNegInf;
       int ba = 0x7fffffff;
@@ -771,6 +905,7 @@ int check_batch(const nfst_batch *lat) {
   if (lat->weighted && !lat->arc_w) return NFST_ERR_ARG;
   if (lat->max_rows > NFST_MAX_ROWS || lat->vocab > NFST_MAX_VOCAB) return NFST_ERR_LIMIT;
   if (lat->max_step_words <= 0 || lat->max_step_words > NFST_MAX_STEP_WORDS) return NFST_ERR_LIMIT;
+  if (lat->sweep_waves != 1 && lat->sweep_waves != 2 && lat->sweep_waves != 4) return NFST_ERR_ARG;
   if (((uintptr_t)lat->fwd_stream | (uintptr_t)lat->bwd_stream) & 15) return NFST_ERR_ARG;
   return NFST_OK;
 }
@@ -813,10 +948,20 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  const int64_t lds = (((int64_t)lat->max_rows + 1) / 2 * 2 + ((int64_t)lat->vocab + 1) / 2 * 2) * 8 + (int64_t)kRingWords * 4;
-  if ((rc = set_lds(k_backward, lds))) return rc;
-  hipLaunchKernelGGL(k_backward, dim3(lat->n_lattices), dim3(256), (size_t)lds, (hipStream_t)stream,
-                     *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me);
+  const int64_t lds = (((int64_t)lat->max_rows + 1) / 2 * 2 + ((int64_t)lat->vocab + 1) / 2 * 2) * 8 +
+                      (int64_t)kRingWords * 4;
+#define NFST_LAUNCH_BWD(W)                                                                              \
+  {                                                                                                     \
+    if ((rc = set_lds(k_backward<W>, lds))) return rc;                                                  \
+    hipLaunchKernelGGL(k_backward<W>, dim3(lat->n_lattices), dim3(W * 64), (size_t)lds,                 \
+                       (hipStream_t)stream, *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me); \
+  }
+  switch (lat->sweep_waves) {
+    case 1: NFST_LAUNCH_BWD(1) break;
+    case 2: NFST_LAUNCH_BWD(2) break;
+    default: NFST_LAUNCH_BWD(4) break;
+  }
+#undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
 }
 
@@ -826,11 +971,22 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
+  if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
+  if (((uintptr_t)lat->arc_src | (uintptr_t)lat->arc_dst | (uintptr_t)lat->arc_label) & 15) return NFST_ERR_ARG;
   const int64_t lds = nfst_lds_bytes(lat);
-  if ((rc = set_lds(k_forward_backward, lds))) return rc;
-  hipLaunchKernelGGL(k_forward_backward, dim3(lat->n_lattices), dim3(512), (size_t)lds,
-                     (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64, logz32,
-                     posterior, grad_theta, (float2 *)beta_me);
+#define NFST_LAUNCH_FB(W)                                                                               \
+  {                                                                                                     \
+    if ((rc = set_lds(k_forward_backward<W>, lds))) return rc;                                          \
+    hipLaunchKernelGGL(k_forward_backward<W>, dim3(lat->n_lattices), dim3(FbGeom<W>::kThreads),         \
+                       (size_t)lds, (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64,      \
+                       logz32, posterior, grad_theta, (float2 *)beta_me);                               \
+  }
+  switch (lat->sweep_waves) {
+    case 1: NFST_LAUNCH_FB(1) break;
+    case 2: NFST_LAUNCH_FB(2) break;
+    default: NFST_LAUNCH_FB(4) break;
+  }
+#undef NFST_LAUNCH_FB
   return hip_status(hipGetLastError());
 }
 

@@ -1,6 +1,6 @@
-"""Test helper: replays a packed sweep stream in float64
-log space, checking the schedule's invariants on the way.  Used to validate the
-host packer on CPU, independently of the HIP kernels."""
+"""Test helper: replays a packed tile program in float64 log
+space, checking the schedule's invariants on the way.  Used to validate the host
+packer on CPU, independently of the HIP kernels."""
 import numpy as np
 
 from nfst_amd import _lib
@@ -10,64 +10,76 @@ def replay(lat, b, direction, theta, extra=None):
     """Returns log values (alpha for 'fwd', beta for 'bwd') per row of lattice b."""
     m = lat.meta_host[b]
     n_rows = int(m[_lib.META_N_ROWS])
+    V = lat.vocab
     if direction == "fwd":
         s = lat.fwd_stream.cpu().numpy().view(np.uint32)
         perm = lat.fwd_perm.cpu().numpy()
-        off, steps, start = int(m[_lib.META_FWD_OFF]), int(m[_lib.META_FWD_STEPS]), 0
-        words = int(m[_lib.META_FWD_WORDS])
+        off, tiles, U, slot0, start = (int(m[_lib.META_FWD_OFF]), int(m[_lib.META_FWD_TILES]), int(m[_lib.META_FWD_U]),
+                                       int(m[_lib.META_FWD_SLOT_OFF]), 0)
     else:
         s = lat.bwd_stream.cpu().numpy().view(np.uint32)
         perm = lat.bwd_perm.cpu().numpy()
-        off, steps, start = int(m[_lib.META_BWD_OFF]), int(m[_lib.META_BWD_STEPS]), int(m[_lib.META_SINK])
-        words = int(m[_lib.META_BWD_WORDS])
+        off, tiles, U, slot0, start = (int(m[_lib.META_BWD_OFF]), int(m[_lib.META_BWD_TILES]), int(m[_lib.META_BWD_U]),
+                                       int(m[_lib.META_BWD_SLOT_OFF]), int(m[_lib.META_SINK]))
+    assert U in (1, 2, 4) and off % 64 == 0
+    ST = 64 * (1 + U)
     src = lat.arc_src.cpu().numpy(); dst = lat.arc_dst.cpu().numpy(); lab = lat.arc_label.cpu().numpy()
-    dp_off = int(m[_lib.META_DP_OFF])
     val = np.full(n_rows, -np.inf)
     done = np.zeros(n_rows, bool)
     val[start] = 0.0
     done[start] = True
-    seen_arcs = []
-    base = off
-    arc_base = 0
-    for _ in range(steps):
-        h0, na = int(s[off]), int(s[off + 1])
-        ns, kl, accum = h0 & 0xFFFF, (h0 >> 16) & 0xF, (h0 >> 20) & 1
-        assert 0 <= kl <= 6 and ns >= 1
-        st = s[off + 2: off + 2 + ns + 1]
-        rec = s[off + 3 + ns: off + 3 + ns + na]
-        assert int(st[ns] >> 16) == na and int(st[ns] & 0xFFFF) == 0xFFFF
-        new = {}
-        for i in range(ns):
-            sid, a0, a1 = int(st[i] & 0xFFFF), int(st[i] >> 16), int(st[i + 1] >> 16)
-            assert a0 <= a1 <= na and sid < n_rows
+    seen = []
+    for T in range(tiles):
+        base = off + T * ST
+        ctl = s[base: base + 64]
+        rec = s[base + 64: base + ST].reshape(64, U)
+        pm = perm[slot0 + T * 64 * U: slot0 + (T + 1) * 64 * U].reshape(64, U)
+        gmax = int(ctl[0] >> 20) & 7
+        assert np.all(((ctl >> 20) & 7) == gmax)
+        writes = {}
+        lane = 0
+        while lane < 64:
+            c = int(ctl[lane])
+            g = (c >> 16) & 7
+            size = 1 << g
+            assert g <= gmax and lane % size == 0 and g <= 6
+            leader = (c >> 13) & 1
+            sid = c & 0x1FFF
             terms = []
-            for a in range(a0, a1):
-                other, l = int(rec[a] & 0xFFFF), int(rec[a] >> 16)
-                ca = int(perm[dp_off + arc_base + a])
-                # the record agrees with the canonical arc it stands for
-                assert lab[ca] == l
-                if direction == "fwd":
-                    assert src[ca] == other and dst[ca] == sid
-                else:
-                    assert dst[ca] == other and src[ca] == sid
-                assert done[other], "dependency not finished before use"
-                x = float(theta[l]) + (float(extra[ca]) if extra is not None else 0.0)
-                terms.append(x + val[other])
-                seen_arcs.append(ca)
-            t = np.array(terms)
-            v = -np.inf if len(t) == 0 or np.all(np.isneginf(t)) else t.max() + np.log(np.exp(t - t.max()).sum())
-            if accum:
-                assert sid in new or done[sid] or True
-                v = np.logaddexp(v, val[sid])
-            new[sid] = v
-            val[sid] = v  # accumulate steps read their own earlier partial
-        for sid in new:
+            for r in range(size):
+                cr = int(ctl[lane + r])
+                assert ((cr >> 16) & 7) == g and (cr & 0x1FFF) == sid
+                assert ((cr >> 13) & 1) == (leader if r == 0 else 0)
+                for j in range(U):
+                    ca = int(pm[lane + r, j])
+                    other, l = int(rec[lane + r, j]) & 0xFFFF, int(rec[lane + r, j]) >> 16
+                    if ca < 0:
+                        assert l == V  # the null label
+                        continue
+                    assert leader or r > 0 or True
+                    assert lab[ca] == l
+                    if direction == "fwd":
+                        assert src[ca] == other and dst[ca] == sid
+                    else:
+                        assert dst[ca] == other and src[ca] == sid
+                    assert done[other], "operand state not finished by an earlier tile"
+                    x = float(theta[l]) + (float(extra[ca]) if extra is not None else 0.0)
+                    terms.append(x + val[other])
+                    seen.append(ca)
+            if leader:
+                t = np.array(terms)
+                v = -np.inf if len(t) == 0 or np.all(np.isneginf(t)) else t.max() + np.log(np.exp(t - t.max()).sum())
+                if (c >> 14) & 1:
+                    assert done[sid], "accumulate piece before the state's first piece"
+                    v = np.logaddexp(v, val[sid])
+                assert sid not in writes
+                writes[sid] = v
+            else:
+                assert not terms  # idle lanes carry no arcs
+            lane += size
+        for sid, v in writes.items():
+            val[sid] = v
             done[sid] = True
-        off += 2 + ns + 1 + na
-        arc_base += na
-    assert off - base == words
     n_dp = int(m[_lib.META_N_DP])
-    assert arc_base == n_dp
-    assert sorted(seen_arcs) == sorted(int(a) for a in perm[dp_off: dp_off + n_dp])
-    assert len(set(seen_arcs)) == n_dp  # every DP arc exactly once
+    assert len(seen) == n_dp and len(set(seen)) == n_dp  # every DP arc exactly once
     return val

@@ -123,8 +123,7 @@ def _mixed_batch():
     ]
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(lanes_policy=1), dict(max_step_words=32), dict(sweep_waves=1),
-                                  dict(sweep_waves=2), dict(sweep_waves=1, max_step_words=24), dict(sweep_waves=4)])
+@pytest.mark.parametrize("opts", [dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4)])
 def test_forward_backward_matches_oracle(dev, opts):
     lats = _mixed_batch()
     theta = synth.label_scores(7, 64)
@@ -200,7 +199,7 @@ def test_huge_degree_and_deep_lattices(dev):
     star = synth._finish(204, V, src, lab, dst)
     deep = synth.layered_lattice(5, n_states=1500, avg_degree=10.0, vocab=V, width=1, span=8)
     theta = synth.label_scores(2, V)
-    for opts in (dict(max_step_words=40), dict(), dict(sweep_waves=1), dict(sweep_waves=2, max_step_words=40)):
+    for opts in (dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4)):
         lat = LatticeBatch.from_synth([star, deep], device=dev, **opts)
         r = ops.forward_backward(lat, torch.from_numpy(theta))
         for b, l in enumerate([star, deep]):

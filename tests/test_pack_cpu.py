@@ -76,7 +76,7 @@ def test_dense_and_arc_front_ends_agree():
         assert torch.equal(getattr(a, k), getattr(d, k)), k
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(lanes_policy=1), dict(max_step_words=24), dict(max_step_words=64, lanes_policy=1)])
+@pytest.mark.parametrize("opts", [dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4)])
 def test_streams_replay_to_oracle_values(opts):
     lats = _cases()
     theta = synth.label_scores(9, 64)
@@ -92,20 +92,24 @@ def test_streams_replay_to_oracle_values(opts):
         assert lat.depth[0] >= 2 and lat.sink[0] == l.n_rows - 1
 
 
-def test_huge_degree_state_is_split_into_accumulate_steps():
+def test_huge_degree_state_is_split_into_accumulate_pieces():
     # star: 0 -bos-> 1, 1 -> {2..201} (200 arcs), all -> 202 (in-degree 200), 202 -eos-> sink 203
     V = 256
     src = [0] + [1] * 200 + list(range(2, 202)) + [202]
     lab = [synth.BOS] + list(range(3, 203)) + [5] * 200 + [synth.EOS]
     dst = [1] + list(range(2, 202)) + [202] * 200 + [203]
     l = synth._finish(204, V, src, lab, dst)
-    lat = LatticeBatch.from_synth([l], max_step_words=40)
     theta = synth.label_scores(2, V)
     r = O.forward_backward(l.n_rows, l.src, l.dst, theta[l.label].astype(np.float64))
-    assert np.allclose(replay(lat, 0, "bwd", theta), r["logbeta"], atol=1e-9)
-    assert np.allclose(replay(lat, 0, "fwd", theta), r["logalpha"], atol=1e-9)
-    s = lat.fwd_stream.numpy().view(np.uint32)
-    assert any((int(w) >> 20) & 1 for w in s[: int(lat.meta_host[0][_lib.META_FWD_WORDS])])  # accumulate flag used
+    for U in (1, 2, 4):
+        lat = LatticeBatch.from_synth([l], slots_per_lane=U)
+        assert np.allclose(replay(lat, 0, "bwd", theta), r["logbeta"], atol=1e-9)
+        assert np.allclose(replay(lat, 0, "fwd", theta), r["logalpha"], atol=1e-9)
+    lat = LatticeBatch.from_synth([l], slots_per_lane=1)  # 200 in-arcs > 64 lanes x 1 slot
+    m = lat.meta_host[0]
+    s = lat.fwd_stream.numpy().view(np.uint32)[int(m[_lib.META_FWD_OFF]):][: int(m[_lib.META_FWD_TILES]) * 128]
+    ctl = s.reshape(-1, 128)[:, :64]
+    assert np.any((ctl >> 14) & 1)  # the accumulate flag is used
 
 
 def test_pack_rejects_bad_lattices():
