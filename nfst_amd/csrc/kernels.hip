@@ -345,15 +345,18 @@ struct LdsPlan {
   __host__ __device__ int64_t bwd_bytes() const { return ((int64_t)rows2 + v2) * 8 + (int64_t)kRingWords * 4; }
 };
 
-constexpr int kFbThreads = 256;  // wave 0: beta sweep, wave 1: alpha sweep, all 4: init + posteriors
+// Block size: wave 0 runs the beta sweep, wave 1 the alpha sweep; every wave helps with
+// the initialisation, the row outputs and the posterior pass.  With at most one lattice
+// per CU those phases are latency-bound and get 16 waves; with several lattices per CU the
+// co-resident workgroups hide each other's latencies and 4 waves are cheaper.
 
 // ------------------------------------------------------------------ backward only
 // Wave 0 sweeps the by-source program from the sink; the other waves help with the
 // initialisation and the outputs.
-__global__ __launch_bounds__(kFbThreads) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
-                                                         double *logz64, float *logz32, float2 *beta_me) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
+                                                 double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = kFbThreads;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
@@ -400,12 +403,12 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
 // synchronisation between them; after the one barrier that follows, all four waves
 // stream the canonical arcs once for the posteriors.
-__global__ __launch_bounds__(kFbThreads) void k_forward_backward(
+template <int NT>
+__global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = kFbThreads;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
@@ -451,22 +454,36 @@ __global__ __launch_bounds__(kFbThreads) void k_forward_backward(
     const int ez = __float_as_int(zme.y);
     const bool has_extra = ex.any();
     const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
-    // 4 arcs per lane and iteration with 16-byte loads/stores on the aligned interior
+    // 4 arcs per lane and load with 16-byte loads/stores on the aligned interior; kPB
+    // such groups per iteration, all their loads issued before the first use, so that
+    // 3 * kPB 16-byte loads per lane are in flight (the pass is latency-bound otherwise)
     const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
-    for (int a = v_begin + tid * 4; a < v_end; a += NT * 4) {
-      const int4 s4 = *reinterpret_cast<const int4 *>(lat.arc_src + a);
-      const int4 d4 = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
-      const int4 l4 = *reinterpret_cast<const int4 *>(lat.arc_label + a);
-      const int ss[4] = {s4.x, s4.y, s4.z, s4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w},
-                ll[4] = {l4.x, l4.y, l4.z, l4.w};
-      float pp[4];
+    constexpr int kPB = 4;
+    for (int a0 = v_begin + tid * 4; a0 < v_end; a0 += NT * 4 * kPB) {
+      int4 s4[kPB], d4[kPB], l4[kPB];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pp[q] = (ss[q] != dd[q]) ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
-                                 : 0.0f;
-        if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
+      for (int u = 0; u < kPB; ++u) {
+        const int a = min(a0 + u * NT * 4, v_end - 4);  // clamped: always a valid group
+        s4[u] = *reinterpret_cast<const int4 *>(lat.arc_src + a);
+        d4[u] = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
+        l4[u] = *reinterpret_cast<const int4 *>(lat.arc_label + a);
       }
-      if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+#pragma unroll
+      for (int u = 0; u < kPB; ++u) {
+        const int a = a0 + u * NT * 4;
+        if (a >= v_end) break;
+        const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w}, dd[4] = {d4[u].x, d4[u].y, d4[u].z, d4[u].w},
+                  ll[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w};
+        float pp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          pp[q] = (ss[q] != dd[q])
+                      ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
+                      : 0.0f;
+          if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
+        }
+        if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      }
     }
     // unaligned head and tail (at most 3 arcs each)
     const int n_head = min(v_begin, a_end) - a_begin;
@@ -868,15 +885,34 @@ int64_t nfst_lds_bytes(const nfst_batch *lat) {
   return LdsPlan(lat->max_rows, lat->vocab).fb_bytes();
 }
 
+// number of CUs of the current device (cached per process; 256 on MI355X)
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta, double *logz64,
                   float *logz32, float *beta_me, void *stream) {
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   const int64_t lds = LdsPlan(lat->max_rows, lat->vocab).bwd_bytes();
-  if ((rc = set_lds(k_backward, lds))) return rc;
-  hipLaunchKernelGGL(k_backward, dim3(lat->n_lattices), dim3(kFbThreads), (size_t)lds, (hipStream_t)stream,
-                     *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me);
+#define NFST_LAUNCH_BWD(NT)                                                                            \
+  {                                                                                                    \
+    if ((rc = set_lds(k_backward<NT>, lds))) return rc;                                                \
+    hipLaunchKernelGGL(k_backward<NT>, dim3(lat->n_lattices), dim3(NT), (size_t)lds, (hipStream_t)stream, \
+                       *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me);                     \
+  }
+  if (lat->n_lattices <= cu_count()) NFST_LAUNCH_BWD(512) else NFST_LAUNCH_BWD(256)
+#undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
 }
 
@@ -889,10 +925,18 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
   if (((uintptr_t)lat->arc_src | (uintptr_t)lat->arc_dst | (uintptr_t)lat->arc_label) & 15) return NFST_ERR_ARG;
   const int64_t lds = nfst_lds_bytes(lat);
-  if ((rc = set_lds(k_forward_backward, lds))) return rc;
-  hipLaunchKernelGGL(k_forward_backward, dim3(lat->n_lattices), dim3(kFbThreads), (size_t)lds,
-                     (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64, logz32, posterior,
-                     grad_theta, (float2 *)beta_me);
+#define NFST_LAUNCH_FB(NT)                                                                              \
+  {                                                                                                     \
+    if ((rc = set_lds(k_forward_backward<NT>, lds))) return rc;                                         \
+    hipLaunchKernelGGL(k_forward_backward<NT>, dim3(lat->n_lattices), dim3(NT), (size_t)lds,            \
+                       (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64, logz32, posterior, \
+                       grad_theta, (float2 *)beta_me);                                                  \
+  }
+  const int cus = cu_count();
+  if (lat->n_lattices <= cus) NFST_LAUNCH_FB(1024)
+  else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512)
+  else NFST_LAUNCH_FB(256)
+#undef NFST_LAUNCH_FB
   return hip_status(hipGetLastError());
 }
 
