@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  -- first, so that torch's bundled HIP runtime is the one the process uses
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NFST_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libnfst_hip.so")  # override: diagnostics only
+LIB_PATH = os.path.join(_HERE, "lib", "libnfst_hip.so")
 
 META_WORDS = 16
 (META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_TILES, META_BWD_OFF,

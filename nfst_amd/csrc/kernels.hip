@@ -227,33 +227,81 @@ __device__ __forceinline__ void tile_issue(const uint32_t *g, int tile, uint32_t
     lds_dma4(src + 64 + lane, dst + 64);
   }
 }
-template <int U>
-__device__ __forceinline__ void tile_wait() {
-  // LDS-DMA loads that may stay in flight: those of kRingTiles - 1 tiles
-#ifdef NFST_EXP_NOWAIT
-  return;
-#endif
-  if (U == 2) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+// ---- producer / consumer split --------------------------------------------------
+// The LDS-DMA issue costs the issuing wave ~100 cycles per tile and the sweep is one
+// long dependency chain, so the copy is done by a helper wave of the same workgroup
+// (it would otherwise sit idle until the posterior pass).  Two LDS words per sweep:
+//   land: tiles 0 .. land-1 have landed (written by the loader after a counted vmcnt)
+//   prog: tiles 0 .. prog-1 are consumed, their slots are free (written by the sweep)
+// Both only grow.  LDS accesses of one wave execute in order and LDS is coherent within
+// the CU, so "DMA landed -> store land" / "load land -> read slot" need no barrier.
+constexpr int kInFlight = 6;  // tiles the loader keeps in flight (of the kRingTiles slots)
+
+__device__ __forceinline__ int lds_flag_load(const int *p) {
+  return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ void lds_flag_store(int *p, int v) {
+  __atomic_store_n(p, v, __ATOMIC_RELAXED);
 }
 
-// One sum-product sweep, run by ONE wave.  g: the lattice's tile program (256-byte
-// aligned), ring: kRingWords of LDS owned by this wave, val: alpha or beta (LDS), th:
-// exp-split label weights incl. the null label (LDS), perm: slot -> canonical arc of
-// this program (only read when there are per-arc extras, EXTRA = true).
+template <int OPS, int K>
+__device__ __forceinline__ void vm_wait() {
+  // at most OPS * K LDS-DMA loads of this wave stay in flight
+  constexpr int N = OPS * K;
+  static_assert(N <= 63, "vmcnt is 6 bits");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// loader wave: streams the tile program g into the ring
+template <int U>
+__device__ __forceinline__ void tile_loader(const uint32_t *g, int n_tiles, uint32_t *ring, const int *prog,
+                                            int *land, int lane) {
+  constexpr int OPS = (U == 2) ? 3 : 2;  // LDS-DMA instructions per tile
+  int issued = 0, slot = 0;
+  while (issued < n_tiles) {
+    while (issued - lds_flag_load(prog) >= kRingTiles) __builtin_amdgcn_s_sleep(1);
+    tile_issue<U>(g, issued, ring, slot, lane);
+    ++issued;
+    slot = (slot + 1 == kRingTiles) ? 0 : slot + 1;
+    vm_wait<OPS, kInFlight>();
+    if (issued > kInFlight) lds_flag_store(land, issued - kInFlight);
+  }
+  // drain: publish the last tiles one by one as they land
+  vm_wait<OPS, 5>(); lds_flag_store(land, max(issued - 5, 0));
+  vm_wait<OPS, 4>(); lds_flag_store(land, max(issued - 4, 0));
+  vm_wait<OPS, 3>(); lds_flag_store(land, max(issued - 3, 0));
+  vm_wait<OPS, 2>(); lds_flag_store(land, max(issued - 2, 0));
+  vm_wait<OPS, 1>(); lds_flag_store(land, max(issued - 1, 0));
+  vm_wait<OPS, 0>(); lds_flag_store(land, issued);
+}
+
+// One sum-product sweep, run by ONE wave.  ring: the tile ring its loader fills, val:
+// alpha or beta (LDS), th: exp-split label weights incl. the null label (LDS), perm:
+// slot -> canonical arc of this program (only read when there are per-arc extras).
 template <int U, bool EXTRA>
-__device__ __forceinline__ void tile_sweep(const uint32_t *g, int n_tiles, uint32_t *ring, float2 *val,
-                                           const float2 *th, const Extra ex, const int32_t *__restrict__ perm,
-                                           int lane) {
+__device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int *prog, const int *land,
+                                           float2 *val, const float2 *th, const Extra ex,
+                                           const int32_t *__restrict__ perm, int lane) {
   if (n_tiles <= 0) return;
-  const int last = n_tiles - 1;
-  for (int T = 0; T < kRingTiles; ++T) tile_issue<U>(g, min(T, last), ring, T, lane);
-  tile_wait<U>();  // tile 0 (and more) has landed
+  while (lds_flag_load(land) < 1) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
   TileRegs<U> cur;
   tile_fetch<U>(ring, 0, lane, cur);
   int slot = 0;  // T % kRingTiles
   for (int T = 0; T < n_tiles; ++T) {
     const int slot_next = (slot + 1 == kRingTiles) ? 0 : slot + 1;
+    int landed = lds_flag_load(land);  // issued first: it is back before the gathers
     // --- gathers of this tile
     float2 tw[U], vv[U];
 #pragma unroll
@@ -261,12 +309,13 @@ __device__ __forceinline__ void tile_sweep(const uint32_t *g, int n_tiles, uint3
       tw[j] = th[cur.rc[j] >> 16];
       vv[j] = val[cur.rc[j] & 0xffffu];
     }
-    // --- ring: this tile's slot is dead (its words are in registers): refill it, then
-    // make sure tile T+1 has landed and fetch its static data
-#ifndef NFST_EXP_NODMA
-    tile_issue<U>(g, min(T + kRingTiles, last), ring, slot, lane);
-#endif
-    tile_wait<U>();
+    // --- static data of the next tile (the last iteration re-reads a resident slot)
+    const int need = min(T + 2, n_tiles);
+    while (landed < need) {
+      __builtin_amdgcn_s_sleep(1);
+      landed = lds_flag_load(land);
+    }
+    asm volatile("" ::: "memory");
     TileRegs<U> nxt;
     tile_fetch<U>(ring, slot_next, lane, nxt);
     // --- this lane's partial sum with one shared exponent
@@ -305,22 +354,33 @@ __device__ __forceinline__ void tile_sweep(const uint32_t *g, int n_tiles, uint3
       }
       val[sid] = me_pack(M, E);
     }
+    // tile T's slot is free: its words were in registers before this iteration, and the
+    // reads of tile T+1's words are complete by the time iteration T+1 publishes T+2
+    lds_flag_store(prog, T + 1);
     cur = nxt;
     slot = slot_next;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight
 }
 
-__device__ __forceinline__ void tile_sweep_u(int U, const uint32_t *g, int n_tiles, uint32_t *ring, float2 *val,
-                                             const float2 *th, const Extra ex, const int32_t *perm, int lane) {
+// role dispatch: wave `consumer` sweeps, wave `loader` feeds it
+__device__ __forceinline__ void run_sweep(bool is_consumer, int U, const uint32_t *g, int n_tiles, uint32_t *ring,
+                                          int *flags, float2 *val, const float2 *th, const Extra ex,
+                                          const int32_t *perm, int lane) {
+  int *prog = flags, *land = flags + 1;
+  if (!is_consumer) {
+    if (U == 4) tile_loader<4>(g, n_tiles, ring, prog, land, lane);
+    else if (U == 2) tile_loader<2>(g, n_tiles, ring, prog, land, lane);
+    else tile_loader<1>(g, n_tiles, ring, prog, land, lane);
+    return;
+  }
   if (ex.any()) {
-    if (U == 4) tile_sweep<4, true>(g, n_tiles, ring, val, th, ex, perm, lane);
-    else if (U == 2) tile_sweep<2, true>(g, n_tiles, ring, val, th, ex, perm, lane);
-    else tile_sweep<1, true>(g, n_tiles, ring, val, th, ex, perm, lane);
+    if (U == 4) tile_sweep<4, true>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
+    else if (U == 2) tile_sweep<2, true>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
+    else tile_sweep<1, true>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
   } else {
-    if (U == 4) tile_sweep<4, false>(g, n_tiles, ring, val, th, ex, perm, lane);
-    else if (U == 2) tile_sweep<2, false>(g, n_tiles, ring, val, th, ex, perm, lane);
-    else tile_sweep<1, false>(g, n_tiles, ring, val, th, ex, perm, lane);
+    if (U == 4) tile_sweep<4, false>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
+    else if (U == 2) tile_sweep<2, false>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
+    else tile_sweep<1, false>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
   }
 }
 
@@ -336,13 +396,13 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
 
 // ------------------------------------------------------------------ LDS layout
 // [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V + null label)]
-// [label histogram: v4 float][ring 0: 3840 words][ring 1: 3840 words]   (all 16-B aligned)
+// [label histogram: v4 float][ring 0: 3840 words][ring 1: 3840 words][4 flag words]  (16-B aligned)
 struct LdsPlan {
   int rows2, v2, v4;
   __host__ __device__ LdsPlan(int max_rows, int vocab)
       : rows2((max_rows + 1) & ~1), v2((vocab + 2) & ~1), v4((vocab + 3) & ~3) {}
-  __host__ __device__ int64_t fb_bytes() const { return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)kRingWords * 4; }
-  __host__ __device__ int64_t bwd_bytes() const { return ((int64_t)rows2 + v2) * 8 + (int64_t)kRingWords * 4; }
+  __host__ __device__ int64_t fb_bytes() const { return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)kRingWords * 4 + 16; }
+  __host__ __device__ int64_t bwd_bytes() const { return ((int64_t)rows2 + v2) * 8 + (int64_t)kRingWords * 4 + 16; }
 };
 
 // Block size: wave 0 runs the beta sweep, wave 1 the alpha sweep; every wave helps with
@@ -366,13 +426,17 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
-  if (tid == 0) beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+  int *flags = (int *)(ring + kRingWords);
+  if (tid == 0) {
+    beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+    flags[0] = 0; flags[1] = 0;
+  }
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wv == 0)
-    tile_sweep_u(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, beta, th, ex,
-                 lat.bwd_perm + m.bwd_slot_off, lane);
+  if (wv < 2)  // wave 0 sweeps, wave 1 streams the tile program into its ring
+    run_sweep(wv == 0, m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, flags, beta, th, ex,
+              lat.bwd_perm + m.bwd_slot_off, lane);
   __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -401,8 +465,8 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 }
 
 // Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
-// synchronisation between them; after the one barrier that follows, all four waves
-// stream the canonical arcs once for the posteriors.
+// synchronisation between them, fed by waves 2 and 3; after the one barrier that
+// follows every wave of the block streams canonical arcs for the posteriors.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
@@ -424,19 +488,45 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   __syncthreads();
+  int *flags = (int *)(ring + 2 * kRingWords);
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     alpha[0] = make_float2(0.5f, __int_as_float(1));
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
   }
   __syncthreads();
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wv == 0)
-    tile_sweep_u(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, beta, th, ex,
-                 lat.bwd_perm + m.bwd_slot_off, lane);
-  else if (wv == 1)
-    tile_sweep_u(m.fwd_u, lat.fwd_stream + m.fwd_off, m.fwd_tiles, ring + kRingWords, alpha, th, ex,
-                 lat.fwd_perm + m.fwd_slot_off, lane);
+  const bool want_post = posterior != nullptr || grad_theta != nullptr;
+  const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
+  // the posterior pass works on groups of 4 arcs (16-byte loads / stores) over the
+  // aligned interior [v_begin, v_end) of the lattice's canonical arc range
+  const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
+  // The waves beyond the first four have nothing to do during the sweeps: they fetch
+  // their first kPre arc groups into registers now, so that after the sweeps the
+  // posterior pass starts on data that is already there.
+  constexpr int kSweepThreads = 256;
+  constexpr int kHelpers = NT - kSweepThreads;
+  constexpr int kPre = (kHelpers > 0) ? 4 : 0;
+  int4 ps[kPre > 0 ? kPre : 1], pd[kPre > 0 ? kPre : 1], pl[kPre > 0 ? kPre : 1];
+  if (kPre > 0 && tid >= kSweepThreads && want_post) {
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
+      if (a < v_end) {
+        ps[u] = *reinterpret_cast<const int4 *>(lat.arc_src + a);
+        pd[u] = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
+        pl[u] = *reinterpret_cast<const int4 *>(lat.arc_label + a);
+      }
+    }
+  }
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 stream their tile programs
+  if (wv == 0 || wv == 2)
+    run_sweep(wv == 0, m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, flags, beta, th, ex,
+              lat.bwd_perm + m.bwd_slot_off, lane);
+  else if (wv == 1 || wv == 3)
+    run_sweep(wv == 1, m.fwd_u, lat.fwd_stream + m.fwd_off, m.fwd_tiles, ring + kRingWords, flags + 2, alpha, th,
+              ex, lat.fwd_perm + m.fwd_slot_off, lane);
   __syncthreads();
   const float2 zme = beta[0];
   if (tid == 0) {
@@ -444,22 +534,42 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     if (logz64) logz64[b] = z;
     if (logz32) logz32[b] = (float)z;
   }
-  for (int i = tid; i < m.n_rows; i += NT) {
-    if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
-    if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
-    if (beta_me) beta_me[m.row_off + i] = beta[i];
+  const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
+  const int ez = __float_as_int(zme.y);
+  const bool has_extra = ex.any();
+  auto do_group = [&](const int4 s4, const int4 d4, const int4 l4, int a) {
+    const int ss[4] = {s4.x, s4.y, s4.z, s4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w};
+    float pp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pp[q] = (ss[q] != dd[q]) ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
+                               : 0.0f;
+      if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
+    }
+    if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  };
+  if (kPre > 0 && tid >= kSweepThreads) {
+    if (want_post) {
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
+        if (a < v_end) do_group(ps[u], pd[u], pl[u], a);
+      }
+    }
+  } else {
+    // the sweep waves (all waves when there are no helpers) write the row outputs
+    constexpr int RT = (kPre > 0) ? kSweepThreads : NT;
+    for (int i = tid; i < m.n_rows; i += RT) {
+      if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
+      if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
+      if (beta_me) beta_me[m.row_off + i] = beta[i];
+    }
   }
-  if (posterior || grad_theta) {
-    const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
-    const int ez = __float_as_int(zme.y);
-    const bool has_extra = ex.any();
-    const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
-    // 4 arcs per lane and load with 16-byte loads/stores on the aligned interior; kPB
-    // such groups per iteration, all their loads issued before the first use, so that
-    // 3 * kPB 16-byte loads per lane are in flight (the pass is latency-bound otherwise)
-    const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
+  if (want_post) {
+    // the arc groups that were not preloaded: kPB groups per iteration, all loads issued
+    // before the first use (3 * kPB 16-byte loads per lane in flight)
     constexpr int kPB = 4;
-    for (int a0 = v_begin + tid * 4; a0 < v_end; a0 += NT * 4 * kPB) {
+    for (int a0 = v_begin + 4 * (kPre * kHelpers + tid); a0 < v_end; a0 += NT * 4 * kPB) {
       int4 s4[kPB], d4[kPB], l4[kPB];
 #pragma unroll
       for (int u = 0; u < kPB; ++u) {
@@ -472,17 +582,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       for (int u = 0; u < kPB; ++u) {
         const int a = a0 + u * NT * 4;
         if (a >= v_end) break;
-        const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w}, dd[4] = {d4[u].x, d4[u].y, d4[u].z, d4[u].w},
-                  ll[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w};
-        float pp[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          pp[q] = (ss[q] != dd[q])
-                      ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
-                      : 0.0f;
-          if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
-        }
-        if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        do_group(s4[u], d4[u], l4[u], a);
       }
     }
     // unaligned head and tail (at most 3 arcs each)

@@ -1,0 +1,135 @@
+"""The host-side mirrors of the reference's Python interface (LatticeScorer, Sampler,
+Estimators, JointProb) driving the HIP engine -- parity with the golden fixtures and
+the oracle.  Needs the MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from nfst_amd import io, synth
+from nfst_amd.estimators import Estimators
+from nfst_amd.joint import JointProb
+from nfst_amd.samplers import Sampler
+from nfst_amd.scorers import LatticeScorer
+
+pytestmark = pytest.mark.gpu
+PAD, BOS, EOS = synth.PAD, synth.BOS, synth.EOS
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_scorer_mirrors_reference_methods(dev, golden_dir):
+    d = load(golden_dir, "gather")
+    K, maxlen = int(d["K"]), int(d["max_length"])
+    V = d["pad7_emission"].shape[2]
+    sc = LatticeScorer(V, pad=PAD, bos=BOS, eos=EOS, max_length=maxlen).to(dev)
+    sc.set_masks(emission=torch.from_numpy(d["pad7_emission"]), transition=torch.from_numpy(d["pad7_transition"]))
+    sc.set_k(K)
+    for r in range(0, 40, 7):
+        st = torch.from_numpy(d["pad7_states"][r]).to(dev)
+        lb = torch.from_numpy(d["pad7_labels"][r]).to(dev)
+        assert np.array_equal(sc.update_fsa_state(lb, st).cpu().numpy(), d["pad7_next"][r])
+        assert np.array_equal(sc.mask_out_invalid(lb, {"state": st, "length": 5}).cpu().numpy(), d["pad7_mask_len5"][r])
+        assert np.array_equal(sc.mask_out_invalid(lb, {"state": st, "length": 21}).cpu().numpy(), d["pad7_mask_len21"][r])
+    with pytest.raises(AssertionError):
+        sc.set_masks(emission=torch.zeros(3, 4), transition=torch.zeros(3, 4, dtype=torch.long))  # scorers.py:878
+
+
+def test_scorer_compute_beta_matches_reference(dev, golden_dir):
+    d = load(golden_dir, "beta_edit")
+    V = d["emission"].shape[1]
+    sc = LatticeScorer(V, theta=torch.from_numpy(d["theta"])).to(dev)
+    sc.set_masks(emission=torch.from_numpy(d["emission"])[None], transition=torch.from_numpy(d["transition"])[None])
+    sc.set_k(3)
+    beta = sc.compute_beta().cpu().numpy()
+    assert beta.shape == (3, d["emission"].shape[0])
+    reach = beta[0] > 0
+    assert np.allclose(beta[0][reach], d["beta_per_sample"][reach], rtol=2e-5)
+    assert np.allclose(beta[0][reach], d["beta_parallel"][reach], rtol=2e-5)  # no parallel arcs in this lattice
+    assert np.array_equal(beta[0], beta[2])
+
+
+def test_sampler_and_iwae_contract(dev, golden_dir):
+    d = load(golden_dir, "iwae")
+    V = d["emission"].shape[2]
+    theta = torch.from_numpy(d["theta"])
+    model = LatticeScorer(V, theta=theta, max_length=48).to(dev)
+    sampler = Sampler(model)
+    B, K = d["emission"].shape[0], 16
+    sampler.set_masks(transition=torch.from_numpy(d["transition"]), emission=torch.from_numpy(d["emission"]))
+    sampler.set_k(K)
+    log_q, samples = sampler.sample(B * K)
+    assert log_q.shape == (B * K,) and samples.dim() == 2 and samples.shape[0] == B * K and samples.dtype == torch.int64
+    s = samples.cpu().numpy()
+    assert np.any(s[:, -1] != PAD)  # the trailing all-pad column is dropped (samplers.py:304-307)
+    # every sample is an accepting path of its lattice (oracle forced walk), log q = score - log Z
+    for b in range(B):
+        src, label, dst, _ = O.dense_to_arcs(d["emission"][b], d["transition"][b])
+        n_rows = d["transition"][b].shape[0]
+        sc = d["theta"][label].astype(np.float64)
+        r = O.forward_backward(n_rows, src, dst, sc)
+        marks = np.concatenate([np.full((K, 1), BOS), s[b * K:(b + 1) * K]], axis=1).astype(np.int32)
+        tot, end = O.score_paths(n_rows, src, label, dst, sc, marks)
+        sink = int(model._lat().sink[b])
+        assert np.all(end == sink)
+        assert np.max(np.abs(tot - r["logZ"] - log_q.cpu().numpy()[b * K:(b + 1) * K])) <= 2e-5
+    # stripping_pad == the reference's loop (oracle restatement) on the reference's own samples
+    ref = d["samples"].reshape(-1, d["samples"].shape[2])
+    got = sampler.stripping_pad(torch.from_numpy(ref).to(dev)).cpu().numpy()
+    assert np.array_equal(got, O.stripping_pad(ref, PAD))
+    # forced scoring of the samples reproduces log q
+    (lq2,) = sampler.sample(B * K, to_evaluate=samples)
+    assert torch.max(torch.abs(lq2 - log_q)) <= 2e-5
+    # IWAE: same 4-tuple as estimatros.py:33-44; exact posterior proposal => zero variance
+    lm, lq, smp, log_w = Estimators.iwae(sampler, model, B, K, 0, None)
+    assert lm.shape == (B,) and lq.shape == (B, K) and smp.shape[:2] == (B, K) and log_w.shape == (B, K)
+    z = Estimators.exact(sampler).detach()
+    bos_score = float(d["theta"][BOS])  # the sampler's implicit bos arc is part of Z but not of the samples
+    assert torch.max(torch.abs(log_w - (z[:, None] - bos_score))) <= 5e-5
+    assert torch.max(torch.abs(lm - (z - bos_score))) <= 5e-5
+
+
+def test_joint_prob_forward_and_decode(dev, tmp_path):
+    V = 48
+    lats = [synth.edit_lattice([10, 11, 12, 13], [20, 21, 22], vocab=V, seed=3),
+            synth.layered_lattice(2, n_states=80, avg_degree=4.0, vocab=V, width=5, span=3)]
+    theta = synth.label_scores(4, V)
+    jp = JointProb(V, pad=PAD, bos=BOS, eos=EOS, k=8, theta=torch.from_numpy(theta)).to(dev)
+    batch = io.collate([(l.dense()[0], l.dense()[1], l.dense()[0], l.dense()[1], np.arange(3), np.arange(4)) for l in lats],
+                       pad=PAD)
+    tb = tuple(torch.from_numpy(x) for x in batch)
+    num, den = jp(*tb)
+    assert den.abs().max() == 0
+    for b, l in enumerate(lats):
+        o = O.forward_backward(l.n_rows, l.src, l.dst, theta[l.label].astype(np.float64))
+        assert abs(float(num[b]) - o["logZ"]) <= 1e-5
+    # training signal: d(-mean log Z)/d theta = -expected mark counts / B
+    (-num.mean()).backward()
+    ref = np.zeros(V)
+    for l in lats:
+        o = O.forward_backward(l.n_rows, l.src, l.dst, theta[l.label].astype(np.float64))
+        ref -= np.bincount(l.label, weights=o["posterior"], minlength=V) / len(lats)
+    assert np.max(np.abs(jp.tilde_p.theta.grad.cpu().numpy() - ref)) <= 1e-4
+    # decode_from_npz (lightning.py:647-658) on a record written in the reference's format
+    em, tr = lats[0].dense()
+    path = os.path.join(tmp_path, "x.npz")
+    io.save_fsa_npz(path, (em, tr), (em, tr), gs=[1, 2], ps=[3])
+    prob, mark = jp.decode_from_npz(path, V, PAD)
+    best, vpath, _ = O.viterbi(lats[0].n_rows, lats[0].src, lats[0].label, lats[0].dst, theta[lats[0].label], 512)
+    o = O.forward_backward(lats[0].n_rows, lats[0].src, lats[0].dst, theta[lats[0].label].astype(np.float64))
+    assert abs(prob - o["logZ"]) <= 1e-5
+    assert np.array_equal(mark.cpu().numpy(), vpath[1:])
+    # the IWAE path of the reference gives the same number with the exact proposal
+    jp2 = JointProb(V, pad=PAD, bos=BOS, eos=EOS, k=8, theta=torch.from_numpy(theta), exact=False).to(dev)
+    num2, _ = jp2(*tb)
+    assert torch.max(torch.abs(num2 - (num.detach() - float(theta[BOS])))) <= 5e-5
