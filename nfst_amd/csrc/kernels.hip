@@ -961,13 +961,26 @@ int hip_status(hipError_t e) { return e == hipSuccess ? NFST_OK : NFST_ERR_HIP; 
 
 constexpr int64_t kMaxLds = 160 * 1024;
 
+// Dynamic LDS above 64 KiB needs a per-kernel opt-in; it is sticky, so it is requested
+// once per kernel and size (hipFuncSetAttribute is slow and not capturable in a graph).
 template <class K>
 int set_lds(K kernel, int64_t bytes) {
   if (bytes > kMaxLds) return NFST_ERR_LIMIT;
-  if (bytes > 64 * 1024)
-    return hip_status(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return NFST_OK;
+  if (bytes <= 64 * 1024) return NFST_OK;
+  static const void *seen_fn[32];
+  static int64_t seen_bytes[32];
+  static int n_seen = 0;
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  for (int i = 0; i < n_seen; ++i)
+    if (seen_fn[i] == fn) {
+      if (seen_bytes[i] >= bytes) return NFST_OK;
+      int rc = hip_status(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      if (rc == NFST_OK) seen_bytes[i] = bytes;
+      return rc;
+    }
+  int rc = hip_status(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (rc == NFST_OK && n_seen < 32) { seen_fn[n_seen] = fn; seen_bytes[n_seen] = bytes; ++n_seen; }
+  return rc;
 }
 
 }  // namespace

@@ -82,20 +82,29 @@ class ForwardBackwardResult(NamedTuple):
 
 
 def forward_backward(lat: LatticeBatch, theta, arc_scores=None, want_alpha_beta=True, want_posterior=True,
-                     want_grad_theta=False, want_me=False) -> ForwardBackwardResult:
+                     want_grad_theta=False, want_me=False,
+                     out: Optional[ForwardBackwardResult] = None) -> ForwardBackwardResult:
     """alpha/beta sweeps, exact log Z and arc posteriors (the quantity the
-    reference only estimates by IWAE, modules/estimatros.py:33-44)."""
+    reference only estimates by IWAE, modules/estimatros.py:33-44).  ``out`` (a
+    previous result of the same batch and flags) is overwritten in place instead of
+    allocating new outputs -- the steady state of a training loop."""
     _need_gpu(lat)
     sc, keep = _scores(lat, theta, arc_scores)
     dev = lat.device
     f32 = dict(dtype=torch.float32, device=dev)
-    la = torch.empty(lat.total_rows, **f32) if want_alpha_beta else None
-    lb = torch.empty(lat.total_rows, **f32) if want_alpha_beta else None
-    z64 = torch.empty(lat.n_lattices, dtype=torch.float64, device=dev)
-    z32 = torch.empty(lat.n_lattices, **f32)
-    post = torch.empty(lat.total_arcs, **f32) if want_posterior else None
-    gth = torch.empty((lat.n_lattices, lat.vocab), **f32) if want_grad_theta else None
-    me = torch.empty((lat.total_rows, 2), **f32) if want_me else None
+    if out is not None:
+        z32, z64, la, lb, post, gth, me = out
+        if ((la is None) == want_alpha_beta or (post is None) == want_posterior or (gth is None) == want_grad_theta
+                or (me is None) == want_me or z64.shape[0] != lat.n_lattices):
+            raise ValueError("`out` was produced with different flags or for another batch")
+    else:
+        la = torch.empty(lat.total_rows, **f32) if want_alpha_beta else None
+        lb = torch.empty(lat.total_rows, **f32) if want_alpha_beta else None
+        z64 = torch.empty(lat.n_lattices, dtype=torch.float64, device=dev)
+        z32 = torch.empty(lat.n_lattices, **f32)
+        post = torch.empty(lat.total_arcs, **f32) if want_posterior else None
+        gth = torch.empty((lat.n_lattices, lat.vocab), **f32) if want_grad_theta else None
+        me = torch.empty((lat.total_rows, 2), **f32) if want_me else None
     check(lib.nfst_forward_backward(C.byref(lat.c_struct()), C.byref(sc), _ptr(la), _ptr(lb), _ptr(z64), _ptr(z32),
                                     _ptr(post), _ptr(gth), _ptr(me), _stream()), "nfst_forward_backward")
     return ForwardBackwardResult(z32, z64, la, lb, post, gth, me)
