@@ -33,6 +33,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per k_forward_backward launch from the committed rocprofv3 PMC passes
+    (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in separate runs of this benchmark, KiB per
+    dispatch).  gfx950 correction from MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 64 B per
+    128-B request of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return (2.0 * d["FETCH_SIZE"]["mean_per_dispatch_KiB"] + d["WRITE_SIZE"]["mean_per_dispatch_KiB"]) * 1024.0, \
+            os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(lats, theta, budget_s=12.0):
     """The oracle (a port of the reference's path-sum semantics, float64) timed on
     the host cores over the same lattices; repeated until ~budget_s of work."""
@@ -168,6 +185,7 @@ def main():
         total_arcs = int(a.item())
     if rank == 0:
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        tbytes, tsrc = pmc_traffic_bytes() if (args.mode == "fb" and B == 256 and args.width == 16) else (None, None)
         out = {
             "metric": "lattice-arcs/sec forward-backward (log-Z)",
             "value": total_arcs * args.steps / dt,
@@ -186,7 +204,9 @@ def main():
                        "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
                        "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()), "host_pack_s": pack_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,
+                         "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
                          "kernel": "k_forward_backward", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
