@@ -114,11 +114,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl" on ROCm) over xGMI; NFST_BENCH_BACKEND=gloo only to rehearse the multi-rank
+        # code path on a box where several ranks must share one GPU
+        backend = os.environ.get("NFST_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from nfst_amd import ops, synth
     from nfst_amd.lattice import LatticeBatch
@@ -147,12 +154,21 @@ def main():
             return ops.backward(lat, theta, want_logbeta=False)
         return state["out"]
 
+    pending = {"work": None}
+
+    def reduce_loss(r):
+        """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously: the collective
+        of step t overlaps the sweep of step t+1; at most one is in flight"""
+        loss = r.logz64.sum()
+        if world > 1:
+            if pending["work"] is not None:
+                pending["work"].wait()
+            loss, pending["work"] = all_reduce_loss(loss, async_op=True)
+        return loss
+
     def step():
         r = run()
-        loss = r.logz64.sum()  # the scalar that is all-reduced: sum of log Z (the loss is its negative)
-        if world > 1:
-            loss = all_reduce_loss(loss)
-        return r, loss
+        return r, reduce_loss(r)
 
     for _ in range(args.warmup):
         step()
@@ -166,9 +182,9 @@ def main():
         ev[i][0].record()
         r = run()
         ev[i][1].record()
-        loss = r.logz64.sum()
-        if world > 1:
-            loss = all_reduce_loss(loss)
+        loss = reduce_loss(r)
+    if pending["work"] is not None:
+        pending["work"].wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
