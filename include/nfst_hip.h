@@ -126,6 +126,8 @@ typedef struct nfst_batch {
   const uint32_t *bwd_stream;/* [bwd_words] */
   const int32_t *fwd_perm;   /* [fwd_slots] tile slot -> canonical arc, -1 = empty slot */
   const int32_t *bwd_perm;   /* [bwd_slots] */
+  const uint32_t *arc_sd;    /* [total_arcs + 8] src | dst << 16: the canonical arcs in 6 B/arc */
+  const uint16_t *arc_l16;   /* [total_arcs + 8] label            for the posterior pass        */
 } nfst_batch;
 
 const char *nfst_strerror(int code);

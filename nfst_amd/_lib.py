@@ -40,7 +40,7 @@ class Batch(C.Structure):
         ("fwd_words", C.c_int64), ("bwd_words", C.c_int64), ("fwd_slots", C.c_int64), ("bwd_slots", C.c_int64),
         ("meta", C.c_void_p), ("row_ptr", C.c_void_p), ("arc_src", C.c_void_p), ("arc_dst", C.c_void_p),
         ("arc_label", C.c_void_p), ("arc_w", C.c_void_p), ("fwd_stream", C.c_void_p), ("bwd_stream", C.c_void_p),
-        ("fwd_perm", C.c_void_p), ("bwd_perm", C.c_void_p),
+        ("fwd_perm", C.c_void_p), ("bwd_perm", C.c_void_p), ("arc_sd", C.c_void_p), ("arc_l16", C.c_void_p),
     ]
 
 

@@ -263,12 +263,28 @@ __device__ __forceinline__ void vm_wait() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// loader wave: streams the tile program g into the ring
+// loader wave, part 1 (kernel entry, before anything else): the first ring-full of tiles
+// needs no hand-shake, so the copy starts while the other waves still initialise LDS
+template <int U>
+__device__ __forceinline__ void tile_loader_start(const uint32_t *g, int n_tiles, uint32_t *ring, int lane) {
+  const int n = min(n_tiles, kRingTiles);
+  for (int t = 0; t < n; ++t) tile_issue<U>(g, t, ring, t, lane);
+}
+__device__ __forceinline__ void loader_start(int U, const uint32_t *g, int n_tiles, uint32_t *ring, int lane) {
+  if (U == 4) tile_loader_start<4>(g, n_tiles, ring, lane);
+  else if (U == 2) tile_loader_start<2>(g, n_tiles, ring, lane);
+  else tile_loader_start<1>(g, n_tiles, ring, lane);
+}
+
+// loader wave, part 2: streams the rest of the tile program g into the ring
 template <int U>
 __device__ __forceinline__ void tile_loader(const uint32_t *g, int n_tiles, uint32_t *ring, const int *prog,
                                             int *land, int lane) {
   constexpr int OPS = (U == 2) ? 3 : 2;  // LDS-DMA instructions per tile
-  int issued = 0, slot = 0;
+  int issued = min(n_tiles, kRingTiles), slot = 0;  // tile_loader_start issued these
+  // publish what has landed of the first ring-full (at most kInFlight tiles stay in flight)
+  vm_wait<OPS, kInFlight>();
+  if (issued > kInFlight) lds_flag_store(land, issued - kInFlight);
   while (issued < n_tiles) {
     while (issued - lds_flag_load(prog) >= kRingTiles) __builtin_amdgcn_s_sleep(1);
     tile_issue<U>(g, issued, ring, slot, lane);
@@ -423,6 +439,8 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   float2 *beta = lds;
   float2 *th = lds + plan.rows2;
   uint32_t *ring = (uint32_t *)(th + plan.v2);
+  if (__builtin_amdgcn_readfirstlane(tid >> 6) == 1)
+    loader_start(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, lane);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
@@ -481,6 +499,11 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   float2 *th = lds + 2 * plan.rows2;
   float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
   uint32_t *ring = (uint32_t *)(gth + plan.v4);
+  {
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (w0 == 2) loader_start(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, lane);
+    if (w0 == 3) loader_start(m.fwd_u, lat.fwd_stream + m.fwd_off, m.fwd_tiles, ring + kRingWords, lane);
+  }
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -507,16 +530,17 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // posterior pass starts on data that is already there.
   constexpr int kSweepThreads = 256;
   constexpr int kHelpers = NT - kSweepThreads;
-  constexpr int kPre = (kHelpers > 0) ? 4 : 0;
-  int4 ps[kPre > 0 ? kPre : 1], pd[kPre > 0 ? kPre : 1], pl[kPre > 0 ? kPre : 1];
+  constexpr int kPre = (kHelpers > 0) ? 7 : 0;  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice
+  // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
+  uint4 psd[kPre > 0 ? kPre : 1];
+  uint2 plb[kPre > 0 ? kPre : 1];
   if (kPre > 0 && tid >= kSweepThreads && want_post) {
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
       const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
       if (a < v_end) {
-        ps[u] = *reinterpret_cast<const int4 *>(lat.arc_src + a);
-        pd[u] = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
-        pl[u] = *reinterpret_cast<const int4 *>(lat.arc_label + a);
+        psd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
+        plb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
       }
     }
   }
@@ -537,13 +561,14 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
   const int ez = __float_as_int(zme.y);
   const bool has_extra = ex.any();
-  auto do_group = [&](const int4 s4, const int4 d4, const int4 l4, int a) {
-    const int ss[4] = {s4.x, s4.y, s4.z, s4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w};
+  auto do_group = [&](const uint4 sd, const uint2 lb, int a) {
+    const uint32_t sdv[4] = {sd.x, sd.y, sd.z, sd.w};
+    const int ll[4] = {(int)(lb.x & 0xffffu), (int)(lb.x >> 16), (int)(lb.y & 0xffffu), (int)(lb.y >> 16)};
     float pp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      pp[q] = (ss[q] != dd[q]) ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
-                               : 0.0f;
+      const int s0 = (int)(sdv[q] & 0xffffu), d0 = (int)(sdv[q] >> 16);
+      pp[q] = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[ll[q]], rz, ez, has_extra, ex, a + q) : 0.0f;
       if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
     }
     if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -553,7 +578,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
 #pragma unroll
       for (int u = 0; u < kPre; ++u) {
         const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
-        if (a < v_end) do_group(ps[u], pd[u], pl[u], a);
+        if (a < v_end) do_group(psd[u], plb[u], a);
       }
     }
   } else {
@@ -567,22 +592,22 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   }
   if (want_post) {
     // the arc groups that were not preloaded: kPB groups per iteration, all loads issued
-    // before the first use (3 * kPB 16-byte loads per lane in flight)
+    // before the first use
     constexpr int kPB = 4;
     for (int a0 = v_begin + 4 * (kPre * kHelpers + tid); a0 < v_end; a0 += NT * 4 * kPB) {
-      int4 s4[kPB], d4[kPB], l4[kPB];
+      uint4 sd[kPB];
+      uint2 lb[kPB];
 #pragma unroll
       for (int u = 0; u < kPB; ++u) {
         const int a = min(a0 + u * NT * 4, v_end - 4);  // clamped: always a valid group
-        s4[u] = *reinterpret_cast<const int4 *>(lat.arc_src + a);
-        d4[u] = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
-        l4[u] = *reinterpret_cast<const int4 *>(lat.arc_label + a);
+        sd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
+        lb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
       }
 #pragma unroll
       for (int u = 0; u < kPB; ++u) {
         const int a = a0 + u * NT * 4;
         if (a >= v_end) break;
-        do_group(s4[u], d4[u], l4[u], a);
+        do_group(sd[u], lb[u], a);
       }
     }
     // unaligned head and tail (at most 3 arcs each)
@@ -1036,7 +1061,7 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
-  if (((uintptr_t)lat->arc_src | (uintptr_t)lat->arc_dst | (uintptr_t)lat->arc_label) & 15) return NFST_ERR_ARG;
+  if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
   const int64_t lds = nfst_lds_bytes(lat);
 #define NFST_LAUNCH_FB(NT)                                                                              \
   {                                                                                                     \

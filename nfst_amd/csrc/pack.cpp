@@ -224,6 +224,8 @@ Opts read_opts(const nfst_pack_opts *o) {
 struct nfst_packed {
   nfst_batch view{};
   std::vector<int32_t> meta, row_ptr, arc_src, arc_dst, arc_label, fwd_perm, bwd_perm;
+  std::vector<uint32_t> arc_sd;
+  std::vector<uint16_t> arc_l16;
   std::vector<float> arc_w;
   std::vector<uint32_t> fwd, bwd;
 };
@@ -265,6 +267,7 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
   const int64_t slack = 512;
   p->row_ptr.resize(rows + B); p->arc_src.resize(arcs); p->arc_dst.resize(arcs); p->arc_label.resize(arcs);
   if (weighted) p->arc_w.resize(arcs);
+  p->arc_sd.assign(arcs + 8, 0); p->arc_l16.assign(arcs + 8, 0);
   p->fwd.assign(fw + slack, 0); p->bwd.assign(bw + slack, 0); p->fwd_perm.resize(fs); p->bwd_perm.resize(bs);
   parallel_for(B, o.n_threads, [&](int b) {
     Lat &L = lats[b];
@@ -278,6 +281,10 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
       std::memcpy(&p->arc_dst[a0], L.dst.data(), A * 4);
       std::memcpy(&p->arc_label[a0], L.label.data(), A * 4);
       if (weighted) std::memcpy(&p->arc_w[a0], L.w.data(), A * 4);
+      for (size_t i = 0; i < A; ++i) {
+        p->arc_sd[a0 + i] = (uint32_t)L.src[i] | ((uint32_t)L.dst[i] << 16);
+        p->arc_l16[a0 + i] = (uint16_t)L.label[i];
+      }
     }
     if (!L.fwd.empty()) std::memcpy(&p->fwd[m[NFST_META_FWD_OFF]], L.fwd.data(), L.fwd.size() * 4);
     if (!L.bwd.empty()) std::memcpy(&p->bwd[m[NFST_META_BWD_OFF]], L.bwd.data(), L.bwd.size() * 4);
@@ -296,6 +303,7 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
   v.arc_w = weighted ? p->arc_w.data() : nullptr;
   v.fwd_stream = p->fwd.data(); v.bwd_stream = p->bwd.data();
   v.fwd_perm = p->fwd_perm.data(); v.bwd_perm = p->bwd_perm.data();
+  v.arc_sd = p->arc_sd.data(); v.arc_l16 = p->arc_l16.data();
   *out = p;
   return NFST_OK;
 }

@@ -36,7 +36,7 @@ class LatticeBatch:
     the host (numpy) because shapes and offsets are needed to size outputs."""
 
     _FIELDS = ("meta", "row_ptr", "arc_src", "arc_dst", "arc_label", "arc_w", "fwd_stream", "bwd_stream",
-               "fwd_perm", "bwd_perm")
+               "fwd_perm", "bwd_perm", "arc_sd", "arc_l16")
 
     def __init__(self, header: dict, tensors: dict):
         self._h = dict(header)
@@ -66,6 +66,8 @@ class LatticeBatch:
                 "bwd_stream": _view(v.bwd_stream, v.bwd_words, C.c_int32, np.int32),
                 "fwd_perm": _view(v.fwd_perm, v.fwd_slots, C.c_int32, np.int32),
                 "bwd_perm": _view(v.bwd_perm, v.bwd_slots, C.c_int32, np.int32),
+                "arc_sd": _view(v.arc_sd, v.total_arcs + 8, C.c_int32, np.int32),
+                "arc_l16": _view(v.arc_l16, v.total_arcs + 8, C.c_int16, np.int16),
             }
             header = {k: int(getattr(v, k)) for k in ("n_lattices", "vocab", "max_rows", "max_tiles", "weighted", "reserved0",
                                                       "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
