@@ -905,6 +905,106 @@ __device__ __forceinline__ float seq_mask(int v, int t, int prev, int pad, int b
   return mk;
 }
 
+// wave64 all-reduce without LDS traffic: quad permutes and row mirrors (DPP) reduce each
+// row of 16 lanes, v_readlane collects the four row results
+__device__ __forceinline__ float read_lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  return (a + b) + (c + d);
+}
+
+// Streaming version for V % 4 == 0, V <= 1024: every wave keeps RB rows in registers
+// (16-byte loads, RB * NV of them in flight per lane -- the kernel is HBM-bound and would be
+// latency-bound with one row at a time), two-pass softmax per row (max, then sum of exp).
+template <int NV, int RB>
+__global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
+                                                         const int64_t *__restrict__ marks, int T, int V,
+                                                         int pad, int bos, int eos, int max_length,
+                                                         float temp, int normalize, float *out) {
+  __shared__ float part[4];
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t *mk = marks + n * T;
+  const float rtemp = 1.0f / temp;
+  float acc = 0.0f;
+  for (int t0 = wave * RB; t0 < T; t0 += 4 * RB) {
+    float4 v[RB][NV];
+    int lab[RB], prev[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = min(t0 + r, T - 1);  // clamped: rows past the end are loaded but not used
+      const float4 *row = reinterpret_cast<const float4 *>(scores + ((size_t)n * T + t) * V);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const int q = c * 64 + lane;
+        v[r][c] = (4 * q < V) ? row[q] : make_float4(kNegInf, kNegInf, kNegInf, kNegInf);
+      }
+      lab[r] = (int)mk[t];
+      prev[r] = t > 0 ? (int)mk[t - 1] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = t0 + r;
+      if (t >= T) break;
+      float sel;
+      const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
+      const float lraw = scores[((size_t)n * T + t) * V + lab[r]];  // L1/L2 hit: the row was just read
+      const float lx = ((lab[r] == pad ? 0.0f : lraw) + lmsk) / temp + lmsk;
+      if (normalize) {
+        // row-level legality (scorers.py:59-83): hoisted out of the per-column loop
+        const bool first = t == 0;
+        const bool ended = !first && (prev[r] == eos || prev[r] == pad);
+        const bool force = !first && max_length >= 0 && t > max_length && !ended;
+        float mx = kNegInf;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          float *e = reinterpret_cast<float *>(&v[r][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int col = (c * 64 + lane) * 4 + k;
+            bool bad = col == bos;
+            bad |= first ? (col == pad) : (ended ? (col != pad) : (col == pad));
+            bad |= force && col != eos;
+            const float x = (col == pad ? 0.0f : e[k]) * rtemp;
+            e[k] = (bad || col >= V) ? kNegInf : x;
+            mx = fmaxf(mx, e[k]);
+          }
+        }
+        mx = wave_max(mx);
+        float sm = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);  // masked / padding columns: exp(-inf) = 0
+        }
+        sm = wave_sum(sm);
+        sel = lx - (mx + logf(sm));  // an all -inf row gives NaN, like the reference
+      } else {
+        sel = lx;
+      }
+      acc += sel * (lab[r] != pad ? 1.0f : 0.0f);
+    }
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
 __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const int64_t *marks,
                                                       int T, int V, int pad, int bos, int eos,
                                                       int max_length, float temp, int normalize,
@@ -1168,9 +1268,18 @@ int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int3
                       int32_t normalize, float *out, void *stream) {
   if (!scores || !marks || !out || n <= 0 || t <= 0 || vocab <= 0 || !(temp > 0.0f)) return NFST_ERR_ARG;
   if (n > 0x7fffffffll) return NFST_ERR_LIMIT;
-  hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
-                     (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
-                     (int)normalize, out);
+#define NFST_LAUNCH_PLP(NV, RB)                                                                         \
+  hipLaunchKernelGGL((k_path_logprob_v4<NV, RB>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
+                     scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,   \
+                     temp, (int)normalize, out)
+  if (vocab % 4 == 0 && vocab <= 256 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(1, 8);
+  else if (vocab % 4 == 0 && vocab <= 512 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(2, 4);
+  else if (vocab % 4 == 0 && vocab <= 1024 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(4, 2);
+  else
+    hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
+                       (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
+                       (int)normalize, out);
+#undef NFST_LAUNCH_PLP
   return hip_status(hipGetLastError());
 }
 

@@ -330,3 +330,23 @@ def test_baseline_batch_properties_and_oracle(dev):
     # run-to-run determinism of everything but the LDS label histogram
     r2 = ops.forward_backward(lat, torch.from_numpy(theta))
     assert torch.equal(r.posterior, r2.posterior) and torch.equal(r.logz64, r2.logz64)
+
+
+@pytest.mark.parametrize("V,T", [(300, 37), (1000, 11), (301, 9), (64, 300)])
+def test_path_logprob_matches_oracle_all_variants(dev, V, T):
+    """16-byte streaming variants (V % 4 == 0, V <= 1024) and the scalar fallback."""
+    rng = np.random.default_rng(V)
+    N = 5
+    seqs = np.full((N, T), PAD, dtype=np.int64)
+    for n in range(N):
+        L = int(rng.integers(2, T - 1))
+        seqs[n, :L] = rng.integers(3, V, size=L)
+        seqs[n, L] = EOS
+    scores = rng.normal(0, 2.0, size=(N, T, V)).astype(np.float32)
+    for norm, temp, maxlen in ((True, 1.0, 1000), (True, 0.6, 1000), (False, 1.0, 1000), (True, 1.0, T // 2)):
+        ref = O.evaluate_seq(scores, seqs, PAD, BOS, EOS, maxlen, temp=temp, normalize=norm)
+        got = ops.path_logprob(torch.from_numpy(scores).to(dev), torch.from_numpy(seqs).to(dev), pad=PAD, bos=BOS,
+                               eos=EOS, max_length=maxlen, temp=temp, normalize=norm).cpu().numpy().astype(np.float64)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
+        assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) <= 2e-5
