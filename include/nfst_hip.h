@@ -280,10 +280,14 @@ int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, f
  * max_length only eos (max_length < 0 disables); the pad column of scores is
  * zeroed (pad_masking_3d, scorers.py:189-192); positions holding pad contribute
  * 0.  normalize = 0 skips the log_softmax (self_normalized = False).
+ * smoothing in [0,1): 0 = evaluation (gather of the realised mark); > 0 = the
+ * training branch (scorers.py:1502-1528, 1584-1592): weight 1 - smoothing on the
+ * realised mark, smoothing / (legal marks - 1) on the other legal marks, values
+ * clamped to +-1e9.
  */
 int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int32_t t,
                       int32_t vocab, int32_t pad, int32_t bos, int32_t eos, int32_t max_length,
-                      float temp, int32_t normalize, float *out, void *stream);
+                      float temp, int32_t normalize, float smoothing, float *out, void *stream);
 
 /* log_w [B,K] = log_p - log_q ; log_marginal [B] = logsumexp_k(log_w) - log K */
 int nfst_iwae(const float *log_p, const float *log_q, int32_t b, int32_t k, float *log_w,

@@ -934,7 +934,8 @@ template <int NV, int RB>
 __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
                                                          const int64_t *__restrict__ marks, int T, int V,
                                                          int pad, int bos, int eos, int max_length,
-                                                         float temp, int normalize, float *out) {
+                                                         float temp, int normalize, float smoothing,
+                                                         float *out) {
   __shared__ float part[4];
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -964,7 +965,8 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
       const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
       const float lraw = scores[((size_t)n * T + t) * V + lab[r]];  // L1/L2 hit: the row was just read
       const float lx = ((lab[r] == pad ? 0.0f : lraw) + lmsk) / temp + lmsk;
-      if (normalize) {
+      sel = lx;
+      if (normalize || smoothing > 0.0f) {
         // row-level legality (scorers.py:59-83): hoisted out of the per-column loop
         const bool first = t == 0;
         const bool ended = !first && (prev[r] == eos || prev[r] == pad);
@@ -984,18 +986,39 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
             mx = fmaxf(mx, e[k]);
           }
         }
-        mx = wave_max(mx);
-        float sm = 0.0f;
+        float lse = 0.0f;
+        if (normalize) {
+          mx = wave_max(mx);
+          float sm = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NV; ++c) {
-          const float *e = reinterpret_cast<const float *>(&v[r][c]);
+          for (int c = 0; c < NV; ++c) {
+            const float *e = reinterpret_cast<const float *>(&v[r][c]);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);  // masked / padding columns: exp(-inf) = 0
+            for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);  // masked / padding columns: exp(-inf) = 0
+          }
+          sm = wave_sum(sm);
+          lse = mx + logf(sm);
+          sel = lx - lse;  // an all -inf row gives NaN, like the reference
         }
-        sm = wave_sum(sm);
-        sel = lx - (mx + logf(sm));  // an all -inf row gives NaN, like the reference
-      } else {
-        sel = lx;
+        if (smoothing > 0.0f) {
+          // training: label-smoothed target (scorers.py:1502-1528, 1584-1592): weight 1 - s on
+          // the realised mark, s / (cnt - 1) on every other legal mark, values clamped to +-1e9
+          float sx = 0.0f, cnt = 0.0f;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (e[k] > kNegInf) { sx += e[k]; cnt += 1.0f; }
+          }
+          sx = wave_sum(sx);
+          cnt = wave_sum(cnt);
+          const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
+          float rest = sx - cnt * lse;  // sum of the legal marks' values ...
+          float others = cnt;
+          if (lx > kNegInf) { rest -= sel; others -= 1.0f; }  // ... other than the realised one
+          sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
+        }
       }
       acc += sel * (lab[r] != pad ? 1.0f : 0.0f);
     }
@@ -1008,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
 __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const int64_t *marks,
                                                       int T, int V, int pad, int bos, int eos,
                                                       int max_length, float temp, int normalize,
-                                                      float *out) {
+                                                      float smoothing, float *out) {
   __shared__ float part[4];
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1042,6 +1065,25 @@ __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const
     } else {
       const float msk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
       sel = ((lab == pad ? 0.0f : row[lab]) + msk) / temp + msk;
+    }
+    if (smoothing > 0.0f) {
+      // label-smoothed target (scorers.py:1502-1528, 1584-1592)
+      float lse = 0.0f;
+      const float lmsk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
+      const float lx = ((lab == pad ? 0.0f : row[lab]) + lmsk) / temp + lmsk;
+      if (normalize) lse = lx - sel;
+      float sx = 0.0f, cnt = 0.0f;
+      for (int v = lane; v < V; v += 64) {
+        const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
+        const float x = ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+        if (x > kNegInf) { sx += x; cnt += 1.0f; }
+      }
+      sx = wave_sum(sx);
+      cnt = wave_sum(cnt);
+      const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
+      float rest = sx - cnt * lse, others = cnt;
+      if (lx > kNegInf) { rest -= sel; others -= 1.0f; }
+      sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
     }
     acc += sel * (lab != pad ? 1.0f : 0.0f);
   }
@@ -1265,20 +1307,21 @@ int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, f
 
 int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int32_t t, int32_t vocab,
                       int32_t pad, int32_t bos, int32_t eos, int32_t max_length, float temp,
-                      int32_t normalize, float *out, void *stream) {
+                      int32_t normalize, float smoothing, float *out, void *stream) {
   if (!scores || !marks || !out || n <= 0 || t <= 0 || vocab <= 0 || !(temp > 0.0f)) return NFST_ERR_ARG;
+  if (!(smoothing >= 0.0f && smoothing < 1.0f)) return NFST_ERR_ARG;  // scorers.py:1514
   if (n > 0x7fffffffll) return NFST_ERR_LIMIT;
 #define NFST_LAUNCH_PLP(NV, RB)                                                                         \
   hipLaunchKernelGGL((k_path_logprob_v4<NV, RB>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
                      scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,   \
-                     temp, (int)normalize, out)
+                     temp, (int)normalize, smoothing, out)
   if (vocab % 4 == 0 && vocab <= 256 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(1, 8);
   else if (vocab % 4 == 0 && vocab <= 512 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(2, 4);
   else if (vocab % 4 == 0 && vocab <= 1024 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(4, 2);
   else
     hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
                        (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
-                       (int)normalize, out);
+                       (int)normalize, smoothing, out);
 #undef NFST_LAUNCH_PLP
   return hip_status(hipGetLastError());
 }

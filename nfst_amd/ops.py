@@ -273,9 +273,11 @@ def gather_label_scores(lat: LatticeBatch, theta, arc_scores=None) -> torch.Tens
 
 
 def path_logprob(scores: torch.Tensor, marks: torch.Tensor, pad: int = 0, bos: int = 1, eos: int = 2,
-                 max_length: Optional[int] = None, temp: float = 1.0, normalize: bool = True) -> torch.Tensor:
+                 max_length: Optional[int] = None, temp: float = 1.0, normalize: bool = True,
+                 smoothing: float = 0.0) -> torch.Tensor:
     """Fused masks + log_softmax + gather + pad-masked sum over time
-    (StaticRNNScorer.evaluate_seq_with_temp, scorers.py:1564-1611): scores [N,T,V], marks [N,T] -> [N]."""
+    (StaticRNNScorer.evaluate_seq_with_temp, scorers.py:1564-1611): scores [N,T,V], marks [N,T] -> [N].
+    ``smoothing > 0`` selects the training branch (label-smoothed target, scorers.py:1584-1592)."""
     if scores.device.type != "cuda":
         raise RuntimeError("nfst_amd: path_logprob runs on the MI355X only (no CPU fallback)")
     scores = scores.to(torch.float32).contiguous()
@@ -286,7 +288,7 @@ def path_logprob(scores: torch.Tensor, marks: torch.Tensor, pad: int = 0, bos: i
     out = torch.empty(N, dtype=torch.float32, device=scores.device)
     check(lib.nfst_path_logprob(_ptr(scores), _ptr(marks), N, T, V, int(pad), int(bos), int(eos),
                                 -1 if max_length is None else int(max_length), C.c_float(temp), int(bool(normalize)),
-                                _ptr(out), _stream()), "nfst_path_logprob")
+                                C.c_float(smoothing), _ptr(out), _stream()), "nfst_path_logprob")
     return out
 
 

@@ -97,13 +97,14 @@ def test_iwae_and_wfst_fixture(dev, golden_dir):
     assert np.max(np.abs(tot.cpu().numpy() - ref)) <= TOL
 
 
-@pytest.mark.parametrize("tag", ["norm_eval", "norm_eval_temp", "norm_eval_short", "raw_eval"])
+@pytest.mark.parametrize("tag", ["norm_eval", "norm_eval_temp", "norm_eval_short", "raw_eval", "norm_train_smooth"])
 def test_path_logprob_fixture(dev, golden_dir, tag):
-    """evaluate_seq_with_temp of the reference (scorers.py:1530-1614), eval mode."""
+    """evaluate_seq_with_temp of the reference (scorers.py:1530-1614), eval and training mode."""
     d = load(golden_dir, "evalseq")
     maxlen, norm, smooth, training, temp = d[tag + "_cfg"]
     got = ops.path_logprob(torch.from_numpy(d["scores"]).to(dev), torch.from_numpy(d["seqs"]).to(dev), pad=PAD, bos=BOS,
-                           eos=EOS, max_length=int(maxlen), temp=float(temp), normalize=bool(norm)).cpu().numpy()
+                           eos=EOS, max_length=int(maxlen), temp=float(temp), normalize=bool(norm),
+                           smoothing=float(smooth) if training else 0.0).cpu().numpy()
     ref = d[tag]
     same_special = (np.isnan(ref) & np.isnan(got)) | (np.isinf(ref) & (ref == got))
     fin = np.isfinite(ref)
@@ -343,10 +344,13 @@ def test_path_logprob_matches_oracle_all_variants(dev, V, T):
         seqs[n, :L] = rng.integers(3, V, size=L)
         seqs[n, L] = EOS
     scores = rng.normal(0, 2.0, size=(N, T, V)).astype(np.float32)
-    for norm, temp, maxlen in ((True, 1.0, 1000), (True, 0.6, 1000), (False, 1.0, 1000), (True, 1.0, T // 2)):
-        ref = O.evaluate_seq(scores, seqs, PAD, BOS, EOS, maxlen, temp=temp, normalize=norm)
+    for norm, temp, maxlen, smooth in ((True, 1.0, 1000, 0.0), (True, 0.6, 1000, 0.0), (False, 1.0, 1000, 0.0),
+                                       (True, 1.0, T // 2, 0.0), (True, 1.0, 1000, 0.1), (False, 0.8, 1000, 0.2)):
+        ref = O.evaluate_seq(scores, seqs, PAD, BOS, EOS, maxlen, temp=temp, normalize=norm, training=smooth > 0,
+                             smoothing=smooth)
         got = ops.path_logprob(torch.from_numpy(scores).to(dev), torch.from_numpy(seqs).to(dev), pad=PAD, bos=BOS,
-                               eos=EOS, max_length=maxlen, temp=temp, normalize=norm).cpu().numpy().astype(np.float64)
+                               eos=EOS, max_length=maxlen, temp=temp, normalize=norm,
+                               smoothing=smooth).cpu().numpy().astype(np.float64)
         fin = np.isfinite(ref)
         assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
         assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) <= 2e-5
