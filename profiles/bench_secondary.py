@@ -1,0 +1,42 @@
+"""Throughput of the secondary kernels of the path (not the BASELINE metric)."""
+import os, sys, time, json
+sys.path.insert(0, '.')
+import numpy as np, torch
+from nfst_amd import ops, synth
+from nfst_amd.lattice import LatticeBatch
+dev = torch.device('cuda')
+def timeit(f, n=50, w=5):
+    for _ in range(w): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+out = {}
+# path_logprob: N x T x V float32 read once
+N, T, V = 2048, 300, 300
+scores = torch.randn(N, T, V, device=dev)
+marks = torch.randint(3, V, (N, T), device=dev); marks[:, -1] = 2
+t = timeit(lambda: ops.path_logprob(scores, marks, max_length=400))
+out["path_logprob"] = {"shape": [N, T, V], "ms": t * 1e3, "GB/s": N * T * V * 4 / t / 1e9}
+lats = synth.bench_batch(256)
+lat = LatticeBatch.from_synth(lats, device=dev)
+theta = torch.from_numpy(synth.label_scores(1, 256)).to(dev)
+arcs = int(lat.n_dp_arcs.sum())
+t = timeit(lambda: ops.backward(lat, theta, want_logbeta=True))
+out["backward"] = {"ms": t * 1e3, "arcs/s": arcs / t, "GB/s_algorithmic": lat.algorithmic_bytes("backward") / t / 1e9}
+t = timeit(lambda: ops.viterbi(lat, theta), n=10, w=2)
+out["viterbi"] = {"ms": t * 1e3, "arcs/s": arcs / t}
+beta = ops.backward(lat, theta, want_logbeta=False, want_me=True)
+for K in (16, 64):
+    t = timeit(lambda: ops.sample_paths(lat, theta, K, seed=1, beta=beta), n=10, w=2)
+    out[f"sample_paths_K{K}"] = {"ms": t * 1e3, "walks/s": 256 * K / t, "arc-steps/s": 256 * K * 130 / t}
+st = torch.zeros(256 * 64, dtype=torch.int64, device=dev); lb = torch.ones(256 * 64, dtype=torch.int64, device=dev)
+t = timeit(lambda: ops.step(lat, st, lb, k=64))
+out["step_K64"] = {"ms": t * 1e3, "walkers/s": 256 * 64 / t}
+t = timeit(lambda: ops.emission_mask(lat, st, k=64, inp=lb))
+out["emission_mask_K64"] = {"ms": t * 1e3, "GB/s_written": 256 * 64 * 256 * 4 / t / 1e9}
+t = timeit(lambda: ops.gather_label_scores(lat, theta))
+out["gather_label_scores"] = {"ms": t * 1e3, "GB/s": lat.total_arcs * 8 / t / 1e9}
+print(json.dumps(out, indent=1))
