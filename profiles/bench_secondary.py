@@ -1,6 +1,6 @@
 """Throughput of the secondary kernels of the path (not the BASELINE metric)."""
 import os, sys, time, json
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from nfst_amd import ops, synth
 from nfst_amd.lattice import LatticeBatch
