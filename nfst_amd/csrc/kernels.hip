@@ -112,19 +112,25 @@ struct Extra {
 //               [14] accumulate (continuation of a state with more than 64*U arcs)
 //               [16:19) g: the state's lanes are the 2^g-aligned group of 2^g lanes
 //               [20:23) largest g in this tile (same in every lane)
+//               [23] the tile holds an accumulate piece (same in every lane)
 // record:       [0:16) operand state | [16:32) label (vocab = the null label: weight 0)
 //
-// The program does not depend on DP values, so it is prefetched far ahead: every
-// iteration the wave copies one whole tile straight into a ring of kRingTiles tile
-// slots in LDS with global_load_lds (LDS-DMA, no VGPR staging): 16 B/lane covers the
-// first 256 words of a U=4 tile and a 4-B/lane load the last 64; U=2 and U=1 tiles are
-// three / two 4-B/lane loads.  While tile T is computed only tile T+1's words
-// are read from the ring, so slot T % kRingTiles is dead and receives tile
-// T + kRingTiles; a constant counted s_waitcnt vmcnt guarantees tile T+1 has landed.
-// There is no branch in the protocol: tiles past the end of the program re-load the
-// last tile into a slot nobody reads.
-constexpr int kRingTiles = 12;
-constexpr int kRingWords = kRingTiles * 320;  // 15 KiB per sweep (sized for U = 4)
+// The program does not depend on DP values, so a helper wave of the workgroup (the
+// "decoder") runs far ahead of the sweep: it loads tiles from HBM into registers
+// (kLoadAhead tiles in flight), turns every record into what the sweep needs -- the LDS
+// address of the operand and the (mantissa, exponent) weight of the arc, label weight x
+// per-arc extra -- and writes the decoded tile into a ring of R slots in LDS.  The sweep
+// wave reads only decoded tiles: nothing but the dependency chain is left on it.
+//
+// decoded tile, 64 * (1 + 3U) words:
+//   [0, 64)            word 0 per lane: [0:20) LDS byte address of the state's value
+//                      [20:23) g  [23:26) tile gmax  [26] tile has accumulate pieces
+//                      [30] accumulate  [31] leader
+//   [64, 64 + 64U)     U operand LDS byte addresses per lane
+//   then               (m, e) weights, slots (2k, 2k+1) of all lanes in block k (16 B per lane)
+constexpr int kLoadAhead = 6;                   // tiles the decoder keeps in flight
+constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
+constexpr int kMaxRing = 8, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
@@ -148,94 +154,94 @@ __device__ __forceinline__ float dpp_f(float v) {
 // branch); stages 3..5 only when the tile's largest g needs them.  All lanes of a state
 // end with bitwise the same (M, E): max of exponents, one rescale, then the sum.
 template <int STAGES>
-__device__ __forceinline__ void seg_reduce_n(float &M, int &E, int g) {
-  int Em = E;
+__device__ __forceinline__ int seg_max(int Em, int g) {
   if (STAGES >= 1) { const int o = dpp_i<0xB1>(Em); Em = (g >= 1) ? max(Em, o) : Em; }
   if (STAGES >= 2) { const int o = dpp_i<0x4E>(Em); Em = (g >= 2) ? max(Em, o) : Em; }
   if (STAGES >= 3) { const int o = dpp_i<0x141>(Em); Em = (g >= 3) ? max(Em, o) : Em; }
   if (STAGES >= 4) { const int o = dpp_i<0x140>(Em); Em = (g >= 4) ? max(Em, o) : Em; }
   if (STAGES >= 5) { const int o = __shfl_xor(Em, 16); Em = (g >= 5) ? max(Em, o) : Em; }
   if (STAGES >= 6) { const int o = __shfl_xor(Em, 32); Em = (g >= 6) ? max(Em, o) : Em; }
-  M = ldexpf(M, E - Em);
-  E = Em;
+  return Em;
+}
+template <int STAGES>
+__device__ __forceinline__ float seg_sum(float M, int g) {
   if (STAGES >= 1) { const float o = dpp_f<0xB1>(M); M = (g >= 1) ? M + o : M; }
   if (STAGES >= 2) { const float o = dpp_f<0x4E>(M); M = (g >= 2) ? M + o : M; }
   if (STAGES >= 3) { const float o = dpp_f<0x141>(M); M = (g >= 3) ? M + o : M; }
   if (STAGES >= 4) { const float o = dpp_f<0x140>(M); M = (g >= 4) ? M + o : M; }
   if (STAGES >= 5) { const float o = __shfl_xor(M, 16); M = (g >= 5) ? M + o : M; }
   if (STAGES >= 6) { const float o = __shfl_xor(M, 32); M = (g >= 6) ? M + o : M; }
+  return M;
 }
-__device__ __forceinline__ void seg_reduce(float &M, int &E, int g, int gmax) {
-  // two complete variants: the shuffles of the wide one (LDS-routed, they drain the
-  // lgkm queue) must stay out of the common path
-  if (__builtin_expect(gmax > 3, 0)) seg_reduce_n<6>(M, E, g);
-  else seg_reduce_n<3>(M, E, g);
-}
-
-template <int U>
-struct TileRegs {
-  uint32_t ctl;
-  uint32_t rc[U];
-};
-
-template <int U>
-__device__ __forceinline__ void tile_fetch(const uint32_t *ring, int tile_slot, int lane, TileRegs<U> &t) {
-  constexpr int ST = 64 * (1 + U);
-  const uint32_t *base = ring + tile_slot * ST;
-  t.ctl = base[lane];
-  const uint32_t *r = base + 64 + lane * U;
-  if (U == 4) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(r);
-    t.rc[0] = v.x; t.rc[1 % U] = v.y; t.rc[2 % U] = v.z; t.rc[3 % U] = v.w;
-  } else if (U == 2) {
-    const uint2 v = *reinterpret_cast<const uint2 *>(r);
-    t.rc[0] = v.x; t.rc[1 % U] = v.y;
+// The same reduction for groups of up to 8 lanes with the per-lane select replaced by the
+// execution mask: m[s] = lanes whose state owns more than 2^s lanes (wave masks, computed
+// off the dependency chain); a DPP instruction executed under m[s] updates exactly the
+// lanes that take part in stage s and leaves the others as they are, so a stage is ONE
+// vector instruction.  The scalar moves in between also provide the two wait states a
+// DPP read needs after a vector write.  Returns the group's exponent in E, the sum in M.
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_exec(float &M, int &E, uint64_t m0, uint64_t m1, uint64_t m2) {
+  static_assert(STAGES == 2 || STAGES == 3, "");
+  const int e0 = E;
+  int d;
+  uint64_t sv;
+  if (STAGES == 2) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_sub_u32 %[d], %[e0], %[e]\n\t"
+        "v_ldexp_f32 %[m], %[m], %[d]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(M), [e] "+&v"(E), [d] "=&v"(d), [sv] "=&s"(sv)
+        : [m0] "s"(m0), [m1] "s"(m1), [e0] "v"(e0));
   } else {
-    t.rc[0] = r[0];
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_sub_u32 %[d], %[e0], %[e]\n\t"
+        "v_ldexp_f32 %[m], %[m], %[d]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(M), [e] "+&v"(E), [d] "=&v"(d), [sv] "=&s"(sv)
+        : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [e0] "v"(e0));
   }
 }
 
-// LDS-DMA (global_load_lds_*): lane i's `bytes` go to LDS address m0 + i*bytes.  Issued
-// from inline asm on purpose: the compiler then keeps no record of a pending LDS-DMA and
-// does not put s_waitcnt vmcnt(0) in front of every LDS access of the sweep; the counted
-// waits are placed by hand (tile_wait).  Callers must not rely on compiler-generated
-// vmcnt for these loads.
-__device__ __forceinline__ void lds_dma16(const uint32_t *gsrc, uint32_t *lds_dst) {
-  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gsrc) : "m0", "memory");
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_n(float &M, int &E, int g) {
+  const int Em = seg_max<STAGES>(E, g);
+  M = seg_sum<STAGES>(ldexpf(M, E - Em), g);
+  E = Em;
 }
-__device__ __forceinline__ void lds_dma4(const uint32_t *gsrc, uint32_t *lds_dst) {
-  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(l), "v"(gsrc) : "m0", "memory");
-}
-
-// copy of tile `tile` of the program g into ring slot `slot`
-template <int U>
-__device__ __forceinline__ void tile_issue(const uint32_t *g, int tile, uint32_t *ring, int slot, int lane) {
-  constexpr int ST = 64 * (1 + U);
-  const uint32_t *src = g + (size_t)tile * ST;
-  uint32_t *dst = ring + slot * ST;
-  if (U == 4) {
-    lds_dma16(src + lane * 4, dst);
-    lds_dma4(src + 256 + lane, dst + 256);
-  } else if (U == 2) {
-    lds_dma4(src + lane, dst);
-    lds_dma4(src + 64 + lane, dst + 64);
-    lds_dma4(src + 128 + lane, dst + 128);
-  } else {
-    lds_dma4(src + lane, dst);
-    lds_dma4(src + 64 + lane, dst + 64);
-  }
-}
-// ---- producer / consumer split --------------------------------------------------
-// The LDS-DMA issue costs the issuing wave ~100 cycles per tile and the sweep is one
-// long dependency chain, so the copy is done by a helper wave of the same workgroup
-// (it would otherwise sit idle until the posterior pass).  Two LDS words per sweep:
-//   land: tiles 0 .. land-1 have landed (written by the loader after a counted vmcnt)
-//   prog: tiles 0 .. prog-1 are consumed, their slots are free (written by the sweep)
-// Both only grow.  LDS accesses of one wave execute in order and LDS is coherent within
-// the CU, so "DMA landed -> store land" / "load land -> read slot" need no barrier.
-constexpr int kInFlight = 6;  // tiles the loader keeps in flight (of the kRingTiles slots)
 
 __device__ __forceinline__ int lds_flag_load(const int *p) {
   return __atomic_load_n(p, __ATOMIC_RELAXED);
@@ -244,159 +250,314 @@ __device__ __forceinline__ void lds_flag_store(int *p, int v) {
   __atomic_store_n(p, v, __ATOMIC_RELAXED);
 }
 
-template <int OPS, int K>
-__device__ __forceinline__ void vm_wait() {
-  // at most OPS * K LDS-DMA loads of this wave stay in flight
-  constexpr int N = OPS * K;
-  static_assert(N <= 63, "vmcnt is 6 bits");
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) v2u lds_v2u;
+typedef __attribute__((address_space(3))) v4u lds_v4u;
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-// loader wave, part 1 (kernel entry, before anything else): the first ring-full of tiles
-// needs no hand-shake, so the copy starts while the other waves still initialise LDS
-template <int U>
-__device__ __forceinline__ void tile_loader_start(const uint32_t *g, int n_tiles, uint32_t *ring, int lane) {
-  const int n = min(n_tiles, kRingTiles);
-  for (int t = 0; t < n; ++t) tile_issue<U>(g, t, ring, t, lane);
-}
-__device__ __forceinline__ void loader_start(int U, const uint32_t *g, int n_tiles, uint32_t *ring, int lane) {
-  if (U == 4) tile_loader_start<4>(g, n_tiles, ring, lane);
-  else if (U == 2) tile_loader_start<2>(g, n_tiles, ring, lane);
-  else tile_loader_start<1>(g, n_tiles, ring, lane);
-}
+// ---- producer / consumer protocol -------------------------------------------------
+// Two LDS words per sweep, both only grow:
+//   land: tiles 0 .. land-1 are decoded and in the ring (written by the decoder)
+//   prog: tiles 0 .. prog-1 are consumed, their slots are free (written by the sweep)
+// LDS accesses of one wave execute in order and LDS is coherent within the CU, so
+// "write slot -> store land" / "load land -> read slot" need no barrier.
 
-// loader wave, part 2: streams the rest of the tile program g into the ring
-template <int U>
-__device__ __forceinline__ void tile_loader(const uint32_t *g, int n_tiles, uint32_t *ring, const int *prog,
-                                            int *land, int lane) {
-  constexpr int OPS = (U == 2) ? 3 : 2;  // LDS-DMA instructions per tile
-  int issued = min(n_tiles, kRingTiles), slot = 0;  // tile_loader_start issued these
-  // publish what has landed of the first ring-full (at most kInFlight tiles stay in flight)
-  vm_wait<OPS, kInFlight>();
-  if (issued > kInFlight) lds_flag_store(land, issued - kInFlight);
-  while (issued < n_tiles) {
-    while (issued - lds_flag_load(prog) >= kRingTiles) __builtin_amdgcn_s_sleep(1);
-    tile_issue<U>(g, issued, ring, slot, lane);
-    ++issued;
-    slot = (slot + 1 == kRingTiles) ? 0 : slot + 1;
-    vm_wait<OPS, kInFlight>();
-    if (issued > kInFlight) lds_flag_store(land, issued - kInFlight);
-  }
-  // drain: publish the last tiles one by one as they land
-  vm_wait<OPS, 5>(); lds_flag_store(land, max(issued - 5, 0));
-  vm_wait<OPS, 4>(); lds_flag_store(land, max(issued - 4, 0));
-  vm_wait<OPS, 3>(); lds_flag_store(land, max(issued - 3, 0));
-  vm_wait<OPS, 2>(); lds_flag_store(land, max(issued - 2, 0));
-  vm_wait<OPS, 1>(); lds_flag_store(land, max(issued - 1, 0));
-  vm_wait<OPS, 0>(); lds_flag_store(land, issued);
-}
+// raw tiles in flight in the decoder's registers (sized for U = 4)
+struct RawTiles {
+  uint32_t ctl[kLoadAhead];
+  uint32_t rc[kLoadAhead][4];
+  int32_t pm[kLoadAhead][4];   // canonical arcs of the slots (only with per-arc extras)
+  float xa[kLoadAhead][4];     // their table weights / caller scores
+  float xb[kLoadAhead][4];
+};
 
-// One sum-product sweep, run by ONE wave.  ring: the tile ring its loader fills, val:
-// alpha or beta (LDS), th: exp-split label weights incl. the null label (LDS), perm:
-// slot -> canonical arc of this program (only read when there are per-arc extras).
+// every variant writes all four record / arc registers of the set: identical stores in the
+// branches of a run-time dispatch on U keep the register sets out of scratch memory
 template <int U, bool EXTRA>
-__device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int *prog, const int *land,
-                                           float2 *val, const float2 *th, const Extra ex,
-                                           const int32_t *__restrict__ perm, int lane) {
-  if (n_tiles <= 0) return;
-  while (lds_flag_load(land) < 1) __builtin_amdgcn_s_sleep(1);
-  asm volatile("" ::: "memory");
-  TileRegs<U> cur;
-  tile_fetch<U>(ring, 0, lane, cur);
-  int slot = 0;  // T % kRingTiles
-  for (int T = 0; T < n_tiles; ++T) {
-    const int slot_next = (slot + 1 == kRingTiles) ? 0 : slot + 1;
-    int landed = lds_flag_load(land);  // issued first: it is back before the gathers
-    // --- gathers of this tile
-    float2 tw[U], vv[U];
+__device__ __forceinline__ void raw_load(const uint32_t *g, const int32_t *perm, int tile, int lane, RawTiles &w,
+                                         int d) {
+  const uint32_t *base = g + (size_t)tile * (64 * (1 + U));
+  const uint32_t c = base[lane];
+  const uint32_t *r = base + 64 + lane * U;
+  const int32_t *q = perm + (size_t)tile * (64 * U) + lane * U;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  int4 a = make_int4(-1, -1, -1, -1);
+  if (U == 4) {
+    v = *reinterpret_cast<const uint4 *>(r);
+    if (EXTRA) a = *reinterpret_cast<const int4 *>(q);
+  } else if (U == 2) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(r);
+    v.x = t.x; v.y = t.y;
+    if (EXTRA) { const int2 u = *reinterpret_cast<const int2 *>(q); a.x = u.x; a.y = u.y; }
+  } else {
+    v.x = r[0];
+    if (EXTRA) a.x = q[0];
+  }
+  w.ctl[d] = c;
+  w.rc[d][0] = v.x; w.rc[d][1] = v.y; w.rc[d][2] = v.z; w.rc[d][3] = v.w;
+  if (EXTRA) { w.pm[d][0] = a.x; w.pm[d][1] = a.y; w.pm[d][2] = a.z; w.pm[d][3] = a.w; }
+}
+
+// per-arc extras of the tile in register set d (its arc ids have arrived): issued two
+// tiles before they are needed
+template <int U>
+__device__ __forceinline__ void extras_load(const Extra ex, RawTiles &w, int d) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      tw[j] = th[cur.rc[j] >> 16];
-      vv[j] = val[cur.rc[j] & 0xffffu];
-    }
-    // --- static data of the next tile (the last iteration re-reads a resident slot)
-    const int need = min(T + 2, n_tiles);
-    while (landed < need) {
-      __builtin_amdgcn_s_sleep(1);
-      landed = lds_flag_load(land);
-    }
-    asm volatile("" ::: "memory");
-    TileRegs<U> nxt;
-    tile_fetch<U>(ring, slot_next, lane, nxt);
-    // --- this lane's partial sum with one shared exponent
-    float mt[U];
-    int et[U];
+  for (int j = 0; j < U; ++j) {
+    const int arc = w.pm[d][j];
+    w.xa[d][j] = (arc >= 0 && ex.arc_w) ? ex.arc_w[arc] : 0.0f;
+    w.xb[d][j] = (arc >= 0 && ex.arc_scores) ? ex.arc_scores[arc] : 0.0f;
+  }
+}
+
+// decoder wave, part 1 (kernel entry, before anything else): the first loads need
+// nothing from LDS, so they are in flight while the workgroup initialises
+template <bool EXTRA>
+__device__ __forceinline__ void decoder_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, int lane,
+                                              RawTiles &w) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      float mw = tw[j].x;
-      int ew = __float_as_int(tw[j].y);
+  for (int d = 0; d < kLoadAhead; ++d) {
+    if (d < n_tiles) {
+      if (U == 4) raw_load<4, EXTRA>(g, perm, d, lane, w, d);
+      else if (U == 2) raw_load<2, EXTRA>(g, perm, d, lane, w, d);
+      else raw_load<1, EXTRA>(g, perm, d, lane, w, d);
+    }
+  }
+}
+
+// decoder wave, part 2: decodes the tile program g into the ring
+template <int U, bool EXTRA>
+__device__ __forceinline__ void tile_decoder(RawTiles &w, const uint32_t *g, const int32_t *perm, int n_tiles,
+                                             uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
+                                             const float2 *th_, const Extra ex, int lane) {
+  constexpr int D = kLoadAhead;
+  constexpr int SW = 64 * (1 + 3 * U);
+  const lds_v2f *th = (const lds_v2f *)th_;
+  const uint32_t val_base = lds_addr(val);
+  const uint32_t ring_base = lds_addr(ring);
+  int slot = 0, freed = 0;
+  if (EXTRA) {
+    if (n_tiles > 0) extras_load<U>(ex, w, 0);
+    if (n_tiles > 1) extras_load<U>(ex, w, 1);
+  }
+  for (int t0 = 0; t0 < n_tiles; t0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int t = t0 + d;
+      if (t >= n_tiles) break;
+      if (EXTRA && t + 2 < n_tiles) extras_load<U>(ex, w, (d + 2) % D);
+      // --- decode
+      const uint32_t ctl = w.ctl[d];
+      const uint32_t w0 = (val_base + ((ctl & 0x1fffu) << 3)) | ((ctl & 0x00070000u) << 4) |
+                          ((ctl & 0x00f00000u) << 3) | ((ctl & (1u << 13)) << 18) | ((ctl & (1u << 14)) << 16);
+      uint32_t oa[U];
+      v2f tw[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t rc = w.rc[d][j];
+        tw[j] = th[rc >> 16];
+        oa[j] = val_base + ((rc & 0xffffu) << 3);
+      }
       if (EXTRA) {
-        const int arc = perm[(size_t)T * (64 * U) + lane * U + j];
-        if (arc >= 0) {
-          ME x = exp_split(ex.at(arc));
-          mw *= x.m;
-          ew += x.e;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (w.pm[d][j] >= 0) {
+            const ME x = exp_split(w.xa[d][j] + w.xb[d][j]);
+            tw[j].x *= x.m;
+            tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
+          }
         }
       }
-      mt[j] = mw * vv[j].x;
-      et[j] = ew + __float_as_int(vv[j].y);
-    }
-    int E = et[0];
-#pragma unroll
-    for (int j = 1; j < U; ++j) E = max(E, et[j]);
-    float M = ldexpf(mt[0], et[0] - E);
-#pragma unroll
-    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
-    // --- reduce over the state's lanes, normalise, store
-    const int gl = (int)((cur.ctl >> 16) & 7u);
-    const int gmax = (int)((__builtin_amdgcn_readfirstlane(cur.ctl) >> 20) & 7u);
-    seg_reduce(M, E, gl, gmax);
-    if (cur.ctl & (1u << 13)) {
-      const uint32_t sid = cur.ctl & 0x1fffu;
-      if (cur.ctl & (1u << 14)) {
-        const float2 old = val[sid];
-        me_acc(M, E, old.x, __float_as_int(old.y));
+      // --- the slot must be free: tile t - R consumed
+      while (__builtin_expect(t - freed >= R, 0)) {
+        freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
+        if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
       }
-      val[sid] = me_pack(M, E);
+      asm volatile("" ::: "memory");
+      const uint32_t sb = ring_base + (uint32_t)slot * (SW * 4);
+      *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
+      if (U == 4) {
+        *(lds_v4u *)(uintptr_t)(sb + 256 + lane * 16) = v4u{oa[0], oa[1 % U], oa[2 % U], oa[3 % U]};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{tw[2 % U].x, tw[2 % U].y, tw[3 % U].x, tw[3 % U].y};
+      } else if (U == 2) {
+        *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+      } else {
+        *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
+        *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = tw[0];
+      }
+      // --- refill this register set, publish
+      if (t + D < n_tiles) raw_load<U, EXTRA>(g, perm, t + D, lane, w, d);
+      asm volatile("" ::: "memory");
+      lds_flag_store(land, t + 1);
+      slot = (slot + 1 == R) ? 0 : slot + 1;
     }
-    // tile T's slot is free: its words were in registers before this iteration, and the
-    // reads of tile T+1's words are complete by the time iteration T+1 publishes T+2
-    lds_flag_store(prog, T + 1);
-    cur = nxt;
-    slot = slot_next;
   }
 }
 
-// role dispatch: wave `consumer` sweeps, wave `loader` feeds it
-__device__ __forceinline__ void run_sweep(bool is_consumer, int U, const uint32_t *g, int n_tiles, uint32_t *ring,
-                                          int *flags, float2 *val, const float2 *th, const Extra ex,
-                                          const int32_t *perm, int lane) {
-  int *prog = flags, *land = flags + 1;
-  if (!is_consumer) {
-    if (U == 4) tile_loader<4>(g, n_tiles, ring, prog, land, lane);
-    else if (U == 2) tile_loader<2>(g, n_tiles, ring, prog, land, lane);
-    else tile_loader<1>(g, n_tiles, ring, prog, land, lane);
-    return;
-  }
-  if (ex.any()) {
-    if (U == 4) tile_sweep<4, true>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
-    else if (U == 2) tile_sweep<2, true>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
-    else tile_sweep<1, true>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
+// decoded tile in the sweep wave's registers
+template <int U>
+struct TileDec {
+  uint32_t w0;
+  uint32_t opa[U];
+  v2f tw[U];
+};
+
+template <int U>
+__device__ __forceinline__ void dec_fetch(uint32_t ring_base, int slot, int lane, TileDec<U> &d) {
+  constexpr int SW = 64 * (1 + 3 * U);
+  const uint32_t sb = ring_base + (uint32_t)slot * (SW * 4);
+  d.w0 = *(const lds_u32 *)(uintptr_t)(sb + lane * 4);
+  if (U == 4) {
+    const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 256 + lane * 16);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16);
+    const v4f q = *(const lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y; d.opa[2 % U] = a.z; d.opa[3 % U] = a.w;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w}; d.tw[2 % U] = v2f{q.x, q.y}; d.tw[3 % U] = v2f{q.z, q.w};
+  } else if (U == 2) {
+    const v2u a = *(const lds_v2u *)(uintptr_t)(sb + 256 + lane * 8);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w};
   } else {
-    if (U == 4) tile_sweep<4, false>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
-    else if (U == 2) tile_sweep<2, false>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
-    else tile_sweep<1, false>(n_tiles, ring, prog, land, val, th, ex, perm, lane);
+    d.opa[0] = *(const lds_u32 *)(uintptr_t)(sb + 256 + lane * 4);
+    d.tw[0] = *(const lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8);
+  }
+}
+
+// One sum-product sweep, run by ONE wave over the decoded ring.  The sweep is one
+// dependency chain (gather operands -> sum -> reduce over the state's lanes -> store ->
+// next tile's gathers); an iteration starts with the operand gathers of its tile and
+// fetches the next decoded tile in their shadow.
+template <int U>
+__device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land,
+                                           int lane) {
+  if (n_tiles <= 0) return;
+  const uint32_t ring_base = lds_addr(ring);
+  int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
+  auto wait_landed = [&](int need) {
+    while (__builtin_expect(landed < need, 0)) {
+      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (landed < need) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  const int last = n_tiles - 1;
+  int t1 = 0, slot1 = 0;  // tile fetched next: min(T + 1, last), and its ring slot
+  // iteration T: `cur` = tile T, `nxt` receives tile T+1
+  auto step = [&](int T, const TileDec<U> &cur, TileDec<U> &nxt, bool publish) {
+    // --- operand gathers: the head of the dependency chain
+    v2f vv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)cur.opa[j];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the gathers
+    // --- the next decoded tile (the last iteration re-reads the last tile's slot)
+    if (t1 < last) { ++t1; slot1 = (slot1 + 1 == R) ? 0 : slot1 + 1; }
+    wait_landed(t1 + 1);
+    dec_fetch<U>(ring_base, slot1, lane, nxt);
+    asm volatile("" ::: "memory");
+    // --- everything that only needs the tile's control word is computed in the shadow of
+    // the gathers: which reduce variant (wave-uniform: the tile's largest group has up to
+    // 4 lanes, 8 lanes, or is wider / the tile holds continuation pieces of states with
+    // more than 64 U arcs), the per-lane stage masks, the store address
+    const uint32_t w0 = cur.w0;
+    const int gl = (int)((w0 >> 20) & 7u);
+    const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane(w0);
+    lds_v2f *dst = (lds_v2f *)(uintptr_t)(w0 & 0xfffffu);
+    const bool leader = (int)w0 < 0;
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
+                   m2 = __builtin_amdgcn_ballot_w64(gl > 2);
+    const bool general = (cu & (3u << 25)) != 0;
+    const bool three = (cu & (3u << 23)) == (3u << 23);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // --- this lane's partial sum with one shared exponent
+    auto local_sum = [&](float &M, int &E) {
+      float mt[U];
+      int et[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        mt[j] = cur.tw[j].x * vv[j].x;
+        et[j] = __float_as_int(cur.tw[j].y) + __float_as_int(vv[j].y);
+      }
+      E = et[0];
+#pragma unroll
+      for (int j = 1; j < U; ++j) E = max(E, et[j]);
+      M = ldexpf(mt[0], et[0] - E);
+#pragma unroll
+      for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
+    };
+    // --- reduce over the state's lanes (max of exponents, one rescale, sum), normalise,
+    // store.  The branch is taken before the gathers are back; the two
+    // common variants run their stages under execution masks (seg_reduce_exec).
+    float M;
+    int E;
+    if (__builtin_expect(general, 0)) {
+      local_sum(M, E);
+      seg_reduce_n<6>(M, E, gl);
+      if (leader) {
+        if (w0 & (1u << 30)) {
+          const v2f old = *dst;
+          me_acc(M, E, old.x, __float_as_int(old.y));
+        }
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    } else if (three) {
+      local_sum(M, E);
+      seg_reduce_exec<3>(M, E, m0, m1, m2);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    } else {
+      local_sum(M, E);
+      seg_reduce_exec<2>(M, E, m0, m1, m2);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    }
+    // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
+    if (publish) lds_flag_store(prog, T + 2);
+  };
+  wait_landed(1);
+  TileDec<U> da, db;
+  dec_fetch<U>(ring_base, 0, lane, da);
+  asm volatile("" ::: "memory");
+  // two iterations per trip so that the register roles alternate without copies
+  for (int T = 0; T < n_tiles; T += 2) {
+    step(T, da, db, false);
+    if (T + 1 >= n_tiles) break;
+    step(T + 1, db, da, true);
+  }
+}
+
+// role dispatch: one wave sweeps, another decodes for it
+template <bool EXTRA>
+__device__ __forceinline__ void run_sweep(bool is_consumer, int U, RawTiles &w, const uint32_t *g,
+                                          const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
+                                          float2 *val, const float2 *th, const Extra ex, int lane) {
+  int *prog = flags, *land = flags + 1;
+  if (is_consumer) {
+    if (U == 4) tile_sweep<4>(n_tiles, ring, R, prog, land, lane);
+    else if (U == 2) tile_sweep<2>(n_tiles, ring, R, prog, land, lane);
+    else tile_sweep<1>(n_tiles, ring, R, prog, land, lane);
+  } else {
+    if (U == 4) tile_decoder<4, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 2) tile_decoder<2, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
+    else tile_decoder<1, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
   }
 }
 
@@ -412,13 +573,17 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
 
 // ------------------------------------------------------------------ LDS layout
 // [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V + null label)]
-// [label histogram: v4 float][ring 0: 3840 words][ring 1: 3840 words][4 flag words]  (16-B aligned)
+// [label histogram: v4 float][ring 0: R decoded tiles][ring 1: R decoded tiles][4 flag words]  (16-B aligned)
 struct LdsPlan {
   int rows2, v2, v4;
   __host__ __device__ LdsPlan(int max_rows, int vocab)
       : rows2((max_rows + 1) & ~1), v2((vocab + 2) & ~1), v4((vocab + 3) & ~3) {}
-  __host__ __device__ int64_t fb_bytes() const { return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)kRingWords * 4 + 16; }
-  __host__ __device__ int64_t bwd_bytes() const { return ((int64_t)rows2 + v2) * 8 + (int64_t)kRingWords * 4 + 16; }
+  __host__ __device__ int64_t fb_bytes(int R) const {
+    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)R * kSlotWords * 4 + 16;
+  }
+  __host__ __device__ int64_t bwd_bytes(int R) const {
+    return ((int64_t)rows2 + v2) * 8 + (int64_t)R * kSlotWords * 4 + 16;
+  }
 };
 
 // Block size: wave 0 runs the beta sweep, wave 1 the alpha sweep; every wave helps with
@@ -429,8 +594,8 @@ struct LdsPlan {
 // ------------------------------------------------------------------ backward only
 // Wave 0 sweeps the by-source program from the sink; the other waves help with the
 // initialisation and the outputs.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
+template <int NT, bool EXTRA>
+__global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, float *logbeta,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -439,22 +604,23 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   float2 *beta = lds;
   float2 *th = lds + plan.rows2;
   uint32_t *ring = (uint32_t *)(th + plan.v2);
-  if (__builtin_amdgcn_readfirstlane(tid >> 6) == 1)
-    loader_start(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, lane);
+  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RawTiles raw;
+  if (wv == 1)
+    decoder_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, lane, raw);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
-  int *flags = (int *)(ring + kRingWords);
+  int *flags = (int *)(ring + (size_t)R * kSlotWords);
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     flags[0] = 0; flags[1] = 0;
   }
   __syncthreads();
-  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wv < 2)  // wave 0 sweeps, wave 1 streams the tile program into its ring
-    run_sweep(wv == 0, m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, flags, beta, th, ex,
-              lat.bwd_perm + m.bwd_slot_off, lane);
+  if (wv < 2)  // wave 0 sweeps, wave 1 decodes the tile program into its ring
+    run_sweep<EXTRA>(wv == 0, m.bwd_u, raw, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
+              m.bwd_tiles, ring, R, flags, beta, th, ex, lane);
   __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -485,9 +651,9 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
 // synchronisation between them, fed by waves 2 and 3; after the one barrier that
 // follows every wave of the block streams canonical arcs for the posteriors.
-template <int NT>
+template <int NT, bool EXTRA>
 __global__ __launch_bounds__(NT) void k_forward_backward(
-    nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
+    nfst_batch lat, nfst_scores sc, int R, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
@@ -499,11 +665,16 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   float2 *th = lds + 2 * plan.rows2;
   float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
   uint32_t *ring = (uint32_t *)(gth + plan.v4);
-  {
-    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (w0 == 2) loader_start(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, lane);
-    if (w0 == 3) loader_start(m.fwd_u, lat.fwd_stream + m.fwd_off, m.fwd_tiles, ring + kRingWords, lane);
-  }
+  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
+  constexpr bool has_extra = EXTRA;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool bwd_side = (wv == 0 || wv == 2);  // waves 0 / 2: beta sweep and its decoder; 1 / 3: alpha
+  const uint32_t *my_prog = bwd_side ? lat.bwd_stream + m.bwd_off : lat.fwd_stream + m.fwd_off;
+  const int32_t *my_perm = bwd_side ? lat.bwd_perm + m.bwd_slot_off : lat.fwd_perm + m.fwd_slot_off;
+  const int my_tiles = bwd_side ? m.bwd_tiles : m.fwd_tiles;
+  const int my_u = bwd_side ? m.bwd_u : m.fwd_u;
+  RawTiles raw;
+  if (wv == 2 || wv == 3) decoder_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, lane, raw);
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -511,15 +682,13 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   __syncthreads();
-  int *flags = (int *)(ring + 2 * kRingWords);
+  int *flags = (int *)(ring + 2 * (size_t)R * kSlotWords);
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     alpha[0] = make_float2(0.5f, __int_as_float(1));
     flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
   }
   __syncthreads();
-  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool want_post = posterior != nullptr || grad_theta != nullptr;
   const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
   // the posterior pass works on groups of 4 arcs (16-byte loads / stores) over the
@@ -530,7 +699,9 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // posterior pass starts on data that is already there.
   constexpr int kSweepThreads = 256;
   constexpr int kHelpers = NT - kSweepThreads;
-  constexpr int kPre = (kHelpers > 0) ? 7 : 0;  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice
+  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice (fewer with per-arc extras: the decoder
+  // waves need the registers)
+  constexpr int kPre = (kHelpers > 0) ? (EXTRA ? 2 : 7) : 0;
   // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
   uint4 psd[kPre > 0 ? kPre : 1];
   uint2 plb[kPre > 0 ? kPre : 1];
@@ -544,13 +715,10 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       }
     }
   }
-  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 stream their tile programs
-  if (wv == 0 || wv == 2)
-    run_sweep(wv == 0, m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, ring, flags, beta, th, ex,
-              lat.bwd_perm + m.bwd_slot_off, lane);
-  else if (wv == 1 || wv == 3)
-    run_sweep(wv == 1, m.fwd_u, lat.fwd_stream + m.fwd_off, m.fwd_tiles, ring + kRingWords, flags + 2, alpha, th,
-              ex, lat.fwd_perm + m.fwd_slot_off, lane);
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode their tile programs
+  if (wv < 4)
+    run_sweep<EXTRA>(wv < 2, my_u, raw, my_prog, my_perm, my_tiles, bwd_side ? ring : ring + (size_t)R * kSlotWords,
+              R, bwd_side ? flags : flags + 2, bwd_side ? beta : alpha, th, ex, lane);
   __syncthreads();
   const float2 zme = beta[0];
   if (tid == 0) {
@@ -560,7 +728,6 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   }
   const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
   const int ez = __float_as_int(zme.y);
-  const bool has_extra = ex.any();
   auto do_group = [&](const uint4 sd, const uint2 lb, int a) {
     const uint32_t sdv[4] = {sd.x, sd.y, sd.z, sd.w};
     const int ll[4] = {(int)(lb.x & 0xffffu), (int)(lb.x >> 16), (int)(lb.y & 0xffffu), (int)(lb.y >> 16)};
@@ -1162,7 +1329,20 @@ int nfst_device_available(void) {
 
 int64_t nfst_lds_bytes(const nfst_batch *lat) {
   if (!lat) return NFST_ERR_ARG;
-  return LdsPlan(lat->max_rows, lat->vocab).fb_bytes();
+  return LdsPlan(lat->max_rows, lat->vocab).fb_bytes(kMinRing);
+}
+
+// ring slots per sweep: as many as the LDS budget of one workgroup allows (kMinRing .. kMaxRing);
+// with more lattices than CUs two workgroups share a CU's 160 KiB if the lattices are small enough
+static int ring_slots(int64_t fixed_bytes, int n_rings, bool share_cu) {
+  const int64_t slot = (int64_t)kSlotWords * 4 * n_rings;
+  if (share_cu) {
+    const int64_t r = (kMaxLds / 2 - fixed_bytes) / slot;
+    if (r >= kMinRing + 1) return (int)(r > kMaxRing ? kMaxRing : r);
+  }
+  const int64_t r = (kMaxLds - fixed_bytes) / slot;
+  if (r < kMinRing) return 0;
+  return (int)(r > kMaxRing ? kMaxRing : r);
 }
 
 // number of CUs of the current device (cached per process; 256 on MI355X)
@@ -1184,14 +1364,19 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  const int64_t lds = LdsPlan(lat->max_rows, lat->vocab).bwd_bytes();
-#define NFST_LAUNCH_BWD(NT)                                                                            \
+  const LdsPlan plan(lat->max_rows, lat->vocab);
+  const int R = ring_slots(plan.bwd_bytes(0), 1, lat->n_lattices > cu_count());
+  if (R == 0) return NFST_ERR_LIMIT;
+  const int64_t lds = plan.bwd_bytes(R);
+#define NFST_LAUNCH_BWD(NT, EX)                                                                          \
   {                                                                                                    \
-    if ((rc = set_lds(k_backward<NT>, lds))) return rc;                                                \
-    hipLaunchKernelGGL(k_backward<NT>, dim3(lat->n_lattices), dim3(NT), (size_t)lds, (hipStream_t)stream, \
-                       *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me);                     \
+    if ((rc = set_lds(k_backward<NT, EX>, lds))) return rc;                                            \
+    hipLaunchKernelGGL((k_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,             \
+                       (hipStream_t)stream, *lat, *scores, R, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
-  if (lat->n_lattices <= cu_count()) NFST_LAUNCH_BWD(512) else NFST_LAUNCH_BWD(256)
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
+  if (lat->n_lattices <= cu_count()) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
+  else { if (extra) NFST_LAUNCH_BWD(256, true) else NFST_LAUNCH_BWD(256, false) }
 #undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
 }
@@ -1204,18 +1389,24 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if ((rc = check_scores(lat, scores))) return rc;
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
-  const int64_t lds = nfst_lds_bytes(lat);
-#define NFST_LAUNCH_FB(NT)                                                                              \
+  const LdsPlan plan(lat->max_rows, lat->vocab);
+  const int R = ring_slots(plan.fb_bytes(0), 2, lat->n_lattices > cu_count());
+  if (R == 0) return NFST_ERR_LIMIT;
+  const int64_t lds = plan.fb_bytes(R);
+#define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
-    if ((rc = set_lds(k_forward_backward<NT>, lds))) return rc;                                         \
-    hipLaunchKernelGGL(k_forward_backward<NT>, dim3(lat->n_lattices), dim3(NT), (size_t)lds,            \
-                       (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64, logz32, posterior, \
+    if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
+    hipLaunchKernelGGL((k_forward_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,      \
+                       (hipStream_t)stream, *lat, *scores, R, logalpha, logbeta, logz64, logz32, posterior, \
                        grad_theta, (float2 *)beta_me);                                                  \
   }
   const int cus = cu_count();
-  if (lat->n_lattices <= cus) NFST_LAUNCH_FB(1024)
-  else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512)
-  else NFST_LAUNCH_FB(256)
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
+  // (the variants with per-arc extras need ~170 registers: 8 waves per workgroup at most)
+  if (extra) { if (lat->n_lattices <= cus) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(256, true) }
+  else if (lat->n_lattices <= cus) NFST_LAUNCH_FB(1024, false)
+  else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512, false)
+  else NFST_LAUNCH_FB(256, false)
 #undef NFST_LAUNCH_FB
   return hip_status(hipGetLastError());
 }

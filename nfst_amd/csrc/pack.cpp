@@ -75,12 +75,14 @@ void emit_level(const std::vector<int32_t> &states, int U, uint32_t null_label, 
     std::vector<int32_t> pm((size_t)64 * U, -1);
     for (int l = 0; l < 64; ++l) ctl[l] = 0;
     int lane = 0, gmax = 0;
+    bool any_accum = false;
     while (i < head.size()) {
       const Piece &p = head[i];
       const int g = ceil_log2(lanes_of(p));
       const int size = 1 << g;
       if (lane + size > 64) break;
       gmax = std::max(gmax, g);
+      any_accum = any_accum || p.accum;
       for (int r = 0; r < size; ++r) {
         uint32_t c = (uint32_t)p.state | ((uint32_t)g << 16);
         if (r == 0) c |= (1u << 13) | (p.accum ? (1u << 14) : 0u);
@@ -97,7 +99,7 @@ void emit_level(const std::vector<int32_t> &states, int U, uint32_t null_label, 
       lane += size;
       ++i;
     }
-    for (int l = 0; l < 64; ++l) ctl[l] |= (uint32_t)gmax << 20;
+    for (int l = 0; l < 64; ++l) ctl[l] |= ((uint32_t)gmax << 20) | (any_accum ? (1u << 23) : 0u);
     if (stream) {
       stream->insert(stream->end(), ctl, ctl + 64);
       stream->insert(stream->end(), rec.begin(), rec.end());

@@ -17,10 +17,9 @@
 __device__ unsigned long long g_dbg[8192];
 extern "C" int nfst_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long)*8192); }
 namespace {
-#define STAMP(slot) do { if (dbg_on && t >= 20 && t < 52) { unsigned long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory"); if (lane == 0) g_dbg[dbg_base + (t-20)*8 + (slot)] = c_; } } while(0)
+#define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
 
 constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
-constexpr int kViterbiWaves = 4;        // waves of the Viterbi kernel
 constexpr float kNegInf = -__builtin_huge_valf();
 
 struct ME {
@@ -54,8 +53,10 @@ __device__ __forceinline__ void me_acc(float &M, int &E, float mt, int et) {
   M += ldexpf(mt, et - E);
 }
 
+// normalise a sum to mantissa in [0.5, 1).  A zero sum keeps mantissa 0 (frexp(0) = 0,
+// exponent 0): its exponent stays near kEZero, which never wins a max against a real
+// term, so no select is needed.
 __device__ __forceinline__ float2 me_pack(float M, int E) {
-  if (!(M > 0.0f)) return make_float2(0.0f, __int_as_float(kEZero));
   int ex;
   float mant = frexpf(M, &ex);
   return make_float2(mant, __int_as_float(E + ex));
@@ -72,19 +73,19 @@ __device__ __forceinline__ float me_log32(float2 v) {
 }
 
 struct Meta {
-  int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_steps, bwd_off, bwd_steps, sink, n_reach,
-      depth, dp_off, n_dp, fwd_words, bwd_words;
+  int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_tiles, bwd_off, bwd_tiles, sink, n_reach, depth, n_dp,
+      fwd_u, bwd_u, fwd_slot_off, bwd_slot_off;
 };
 __device__ __forceinline__ Meta load_meta(const int32_t *meta, int b) {
   const int32_t *m = meta + (size_t)b * NFST_META_WORDS;
   Meta r;
   r.row_off = m[NFST_META_ROW_OFF]; r.n_rows = m[NFST_META_N_ROWS];
   r.arc_off = m[NFST_META_ARC_OFF]; r.n_arcs = m[NFST_META_N_ARCS];
-  r.fwd_off = m[NFST_META_FWD_OFF]; r.fwd_steps = m[NFST_META_FWD_STEPS];
-  r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_steps = m[NFST_META_BWD_STEPS];
+  r.fwd_off = m[NFST_META_FWD_OFF]; r.fwd_tiles = m[NFST_META_FWD_TILES];
+  r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_tiles = m[NFST_META_BWD_TILES];
   r.sink = m[NFST_META_SINK]; r.n_reach = m[NFST_META_N_REACH]; r.depth = m[NFST_META_DEPTH];
-  r.dp_off = m[NFST_META_DP_OFF]; r.n_dp = m[NFST_META_N_DP];
-  r.fwd_words = m[NFST_META_FWD_WORDS]; r.bwd_words = m[NFST_META_BWD_WORDS];
+  r.n_dp = m[NFST_META_N_DP]; r.fwd_u = m[NFST_META_FWD_U]; r.bwd_u = m[NFST_META_BWD_U];
+  r.fwd_slot_off = m[NFST_META_FWD_SLOT_OFF]; r.bwd_slot_off = m[NFST_META_BWD_SLOT_OFF];
   return r;
 }
 
@@ -102,91 +103,37 @@ struct Extra {
   }
 };
 
-// ---------------------------------------------------------------- LDS ring (LDS-DMA)
-// A sweep consumes its stream strictly front to back and the stream does not
-// depend on the DP values, so it is prefetched far ahead: the sweep's W waves copy
-// 1-KiB chunks straight into a 16 KiB LDS ring with global_load_lds_dwordx4 (no
-// VGPR staging).  The ring is 8 blocks of 512 words (2 chunks each); chunk c is
-// issued by wave c % W and lives in slot c % 16.  A step is at most
-// NFST_MAX_STEP_WORDS = 512 words, so while the read offset is in block b a step
-// (plus the next step's 2-word header) touches blocks b .. b+2 only.  Protocol, run
-// (plus the static data of the following step and the header after that, which the
-// software pipeline reads early) touches blocks b .. b+3 only.  Protocol, run by
-// every wave when the offset enters block b ("crossing", at the top of a step, i.e.
-// after the barrier that ended the previous step):
-//   1. blocks < b are dead: issue the chunks this wave owns of block b+7 into them;
-//   2. counted wait: all of this wave's chunks of blocks <= b+4 have landed
-//      (blocks b+5 .. b+7 may stay in flight -- the constant vmcnt below);
-//   3. the barrier that ends this step publishes block b+4, one crossing before
-//      any wave can read it.
-// The prologue issues blocks 0..7 and waits for blocks 0..4 with the same constant.
-constexpr int kRingWords = 4096;
-constexpr int kRingMask = kRingWords - 1;
-constexpr int kChunkWords = 256;
-constexpr int kBlockShift = 9;  // 512-word blocks
-
-template <int W>
-struct Ring {
-  uint32_t *lds;      // ring base in LDS
-  const uint32_t *g;  // this lattice's stream (256-byte aligned)
-  int total_chunks;
-  int blk;            // block holding the current read offset
-  int w;              // this wave's index within the sweep
-};
-
-template <int W>
-__device__ __forceinline__ void ring_issue_block(const Ring<W> &r, int block, int lane) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int c = 2 * block + q;
-    if ((c % W) != r.w) continue;
-    uint32_t *dst = r.lds + (c & 15) * kChunkWords;
-    if (c < r.total_chunks) {
-      const uint32_t *src = r.g + (size_t)c * kChunkWords + lane * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    } else {
-      // past the end of the stream: a 4-byte-per-lane placeholder load into the (dead)
-      // slot keeps the wave's vmcnt sequence identical, so the constant waits stay exact
-      const uint32_t *src = r.g + lane;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-    }
-  }
-}
-
-template <int W>
-__device__ __forceinline__ void ring_wait() {
-  // chunks a wave may leave in flight: its share of blocks b+5 .. b+7
-  if (W == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (W == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-}
-
-template <int W>
-__device__ __forceinline__ void ring_start(Ring<W> &r, uint32_t *lds, const uint32_t *g, int words, int w,
-                                           int lane) {
-  r.lds = lds; r.g = g; r.total_chunks = (words + kChunkWords - 1) / kChunkWords; r.blk = 0; r.w = w;
-  for (int b = 0; b < 8; ++b) ring_issue_block(r, b, lane);
-  ring_wait<W>();
-}
-
-template <int W>
-__device__ __forceinline__ void ring_advance(Ring<W> &r, int off, int lane) {
-  const int nb = off >> kBlockShift;
-  if (nb != r.blk) {  // a step is at most one block long: nb == blk + 1
-    r.blk = nb;
-    ring_issue_block(r, nb + 7, lane);
-    ring_wait<W>();
-  }
-}
-
-// workgroup barrier that does not drain the LDS-DMA queue (a __syncthreads() would
-// wait vmcnt(0)): this wave's LDS writes are complete, then s_barrier.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
+// ---------------------------------------------------------------- tile programs
+// A sweep is a "tile program" laid out by the host packer (pack.cpp, DESIGN.md
+// section 3): a sequence of fixed-size tiles, each one wave-wide unit of work --
+// 64 control words and 64*U arc records (U = 1, 2 or 4 slots per lane).  ONE wave
+// runs one sweep: its LDS accesses are ordered, a tile only reads states that an
+// earlier tile wrote, so a sweep needs no barrier at all, and the alpha and beta
+// sweeps of a lattice run as two independent waves of the workgroup.
+//
+// control word: [0:13) state id | [13] leader lane (stores the state's sum)
+//               [14] accumulate (continuation of a state with more than 64*U arcs)
+//               [16:19) g: the state's lanes are the 2^g-aligned group of 2^g lanes
+//               [20:23) largest g in this tile (same in every lane)
+//               [23] the tile holds an accumulate piece (same in every lane)
+// record:       [0:16) operand state | [16:32) label (vocab = the null label: weight 0)
+//
+// The program does not depend on DP values, so a helper wave of the workgroup (the
+// "decoder") runs far ahead of the sweep: it loads tiles from HBM into registers
+// (kLoadAhead tiles in flight), turns every record into what the sweep needs -- the LDS
+// address of the operand and the (mantissa, exponent) weight of the arc, label weight x
+// per-arc extra -- and writes the decoded tile into a ring of R slots in LDS.  The sweep
+// wave reads only decoded tiles: nothing but the dependency chain is left on it.
+//
+// decoded tile, 64 * (1 + 3U) words:
+//   [0, 64)            word 0 per lane: [0:20) LDS byte address of the state's value
+//                      [20:23) g  [23:26) tile gmax  [26] tile has accumulate pieces
+//                      [30] accumulate  [31] leader
+//   [64, 64 + 64U)     U operand LDS byte addresses per lane
+//   then               (m, e) weights, slots (2k, 2k+1) of all lanes in block k (16 B per lane)
+constexpr int kLoadAhead = 6;                   // tiles the decoder keeps in flight
+constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
+constexpr int kMaxRing = 8, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
@@ -197,200 +144,438 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// All-reduce of an (M, E) partial sum over groups of 2^KL neighbouring lanes:
-// max of the exponents, one rescale, then the sum.  Quad permutes and half-row /
-// row mirrors are DPP modifiers (no LDS traffic); 32- and 64-lane groups finish with
-// shuffles.  Every lane of a group ends with bitwise the same (M, E).
-template <int KL>
-__device__ __forceinline__ void group_reduce(float &M, int &E) {
-  int Em = E;
-  if (KL >= 1) Em = max(Em, dpp_i<0xB1>(Em));   // quad_perm [1,0,3,2]
-  if (KL >= 2) Em = max(Em, dpp_i<0x4E>(Em));   // quad_perm [2,3,0,1]
-  if (KL >= 3) Em = max(Em, dpp_i<0x141>(Em));  // row_half_mirror
-  if (KL >= 4) Em = max(Em, dpp_i<0x140>(Em));  // row_mirror
-  if (KL >= 5) Em = max(Em, __shfl_xor(Em, 16));
-  if (KL >= 6) Em = max(Em, __shfl_xor(Em, 32));
-  if (KL >= 1) {
-    M = ldexpf(M, E - Em);
-    E = Em;
+// Segmented all-reduce of (M, E) partial sums: a lane whose state owns 2^g lanes takes
+// part in stages 0 .. g-1.  Stage partners: lane^1, lane^2 (quad permutes), 7-lane and
+// 15-lane mirrors inside a row (DPP modifiers, no LDS traffic), then lane^16 and
+// lane^32 (shuffles).  GMAX (the tile's largest g) bounds the stages executed.  All
+// lanes of a state end with bitwise the same (M, E): max of exponents, one rescale,
+// then the sum.
+// Segmented all-reduce of (M, E) partial sums: a lane whose state owns 2^g lanes takes
+// part in stages 0 .. g-1.  Stage partners: lane^1, lane^2 (quad permutes), 7-lane and
+// 15-lane mirrors inside a row (DPP modifiers, no LDS traffic), then lane^16 and
+// lane^32 (shuffles).  Stages 0..2 always run (one predicated select each, no
+// branch); stages 3..5 only when the tile's largest g needs them.  All lanes of a state
+// end with bitwise the same (M, E): max of exponents, one rescale, then the sum.
+template <int STAGES>
+__device__ __forceinline__ int seg_max(int Em, int g) {
+  if (STAGES >= 1) { const int o = dpp_i<0xB1>(Em); Em = (g >= 1) ? max(Em, o) : Em; }
+  if (STAGES >= 2) { const int o = dpp_i<0x4E>(Em); Em = (g >= 2) ? max(Em, o) : Em; }
+  if (STAGES >= 3) { const int o = dpp_i<0x141>(Em); Em = (g >= 3) ? max(Em, o) : Em; }
+  if (STAGES >= 4) { const int o = dpp_i<0x140>(Em); Em = (g >= 4) ? max(Em, o) : Em; }
+  if (STAGES >= 5) { const int o = __shfl_xor(Em, 16); Em = (g >= 5) ? max(Em, o) : Em; }
+  if (STAGES >= 6) { const int o = __shfl_xor(Em, 32); Em = (g >= 6) ? max(Em, o) : Em; }
+  return Em;
+}
+template <int STAGES>
+__device__ __forceinline__ float seg_sum(float M, int g) {
+  if (STAGES >= 1) { const float o = dpp_f<0xB1>(M); M = (g >= 1) ? M + o : M; }
+  if (STAGES >= 2) { const float o = dpp_f<0x4E>(M); M = (g >= 2) ? M + o : M; }
+  if (STAGES >= 3) { const float o = dpp_f<0x141>(M); M = (g >= 3) ? M + o : M; }
+  if (STAGES >= 4) { const float o = dpp_f<0x140>(M); M = (g >= 4) ? M + o : M; }
+  if (STAGES >= 5) { const float o = __shfl_xor(M, 16); M = (g >= 5) ? M + o : M; }
+  if (STAGES >= 6) { const float o = __shfl_xor(M, 32); M = (g >= 6) ? M + o : M; }
+  return M;
+}
+// The same reduction for groups of up to 8 lanes with the per-lane select replaced by the
+// execution mask: m[s] = lanes whose state owns more than 2^s lanes (wave masks, computed
+// off the dependency chain); a DPP instruction executed under m[s] updates exactly the
+// lanes that take part in stage s and leaves the others as they are, so a stage is ONE
+// vector instruction.  The scalar moves in between also provide the two wait states a
+// DPP read needs after a vector write.  Returns the group's exponent in E, the sum in M.
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_exec(float &M, int &E, uint64_t m0, uint64_t m1, uint64_t m2) {
+  static_assert(STAGES == 2 || STAGES == 3, "");
+  const int e0 = E;
+  int d;
+  uint64_t sv;
+  if (STAGES == 2) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_sub_u32 %[d], %[e0], %[e]\n\t"
+        "v_ldexp_f32 %[m], %[m], %[d]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(M), [e] "+&v"(E), [d] "=&v"(d), [sv] "=&s"(sv)
+        : [m0] "s"(m0), [m1] "s"(m1), [e0] "v"(e0));
+  } else {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_sub_u32 %[d], %[e0], %[e]\n\t"
+        "v_ldexp_f32 %[m], %[m], %[d]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(M), [e] "+&v"(E), [d] "=&v"(d), [sv] "=&s"(sv)
+        : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [e0] "v"(e0));
   }
-  if (KL >= 1) M += dpp_f<0xB1>(M);
-  if (KL >= 2) M += dpp_f<0x4E>(M);
-  if (KL >= 3) M += dpp_f<0x141>(M);
-  if (KL >= 4) M += dpp_f<0x140>(M);
-  if (KL >= 5) M += __shfl_xor(M, 16);
-  if (KL >= 6) M += __shfl_xor(M, 32);
 }
 
-// ---------------------------------------------------------------- the sweep proper
-constexpr int kUnroll = 4;  // arcs per lane handled by the straight-line path
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_n(float &M, int &E, int g) {
+  const int Em = seg_max<STAGES>(E, g);
+  M = seg_sum<STAGES>(ldexpf(M, E - Em), g);
+  E = Em;
+}
 
-// scalar description of one step (wave-uniform, lives in SGPRs)
-struct StepHdr {
-  int off, ns, kl, na, st, rec, next_off, arc_base;
-  bool accum;
+__device__ __forceinline__ int lds_flag_load(const int *p) {
+  return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ void lds_flag_store(int *p, int v) {
+  __atomic_store_n(p, v, __ATOMIC_RELAXED);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) v2u lds_v2u;
+typedef __attribute__((address_space(3))) v4u lds_v4u;
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// ---- producer / consumer protocol -------------------------------------------------
+// Two LDS words per sweep, both only grow:
+//   land: tiles 0 .. land-1 are decoded and in the ring (written by the decoder)
+//   prog: tiles 0 .. prog-1 are consumed, their slots are free (written by the sweep)
+// LDS accesses of one wave execute in order and LDS is coherent within the CU, so
+// "write slot -> store land" / "load land -> read slot" need no barrier.
+
+// raw tiles in flight in the decoder's registers (sized for U = 4)
+struct RawTiles {
+  uint32_t ctl[kLoadAhead];
+  uint32_t rc[kLoadAhead][4];
+  int32_t pm[kLoadAhead][4];   // canonical arcs of the slots (only with per-arc extras)
+  float xa[kLoadAhead][4];     // their table weights / caller scores
+  float xb[kLoadAhead][4];
 };
-__device__ __forceinline__ StepHdr make_hdr(int off, uint32_t h0, uint32_t na, int arc_base) {
-  StepHdr h;
-  h.off = off; h.ns = (int)(h0 & 0xffffu); h.kl = (int)((h0 >> 16) & 0xfu); h.na = (int)na;
-  h.accum = ((h0 >> 20) & 1u) != 0;
-  h.st = off + 2; h.rec = h.st + h.ns + 1; h.next_off = h.rec + h.na; h.arc_base = arc_base;
-  return h;
+
+// every variant writes all four record / arc registers of the set: identical stores in the
+// branches of a run-time dispatch on U keep the register sets out of scratch memory
+template <int U, bool EXTRA>
+__device__ __forceinline__ void raw_load(const uint32_t *g, const int32_t *perm, int tile, int lane, RawTiles &w,
+                                         int d) {
+  const uint32_t *base = g + (size_t)tile * (64 * (1 + U));
+  const uint32_t c = base[lane];
+  const uint32_t *r = base + 64 + lane * U;
+  const int32_t *q = perm + (size_t)tile * (64 * U) + lane * U;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  int4 a = make_int4(-1, -1, -1, -1);
+  if (U == 4) {
+    v = *reinterpret_cast<const uint4 *>(r);
+    if (EXTRA) a = *reinterpret_cast<const int4 *>(q);
+  } else if (U == 2) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(r);
+    v.x = t.x; v.y = t.y;
+    if (EXTRA) { const int2 u = *reinterpret_cast<const int2 *>(q); a.x = u.x; a.y = u.y; }
+  } else {
+    v.x = r[0];
+    if (EXTRA) a.x = q[0];
+  }
+  w.ctl[d] = c;
+  w.rc[d][0] = v.x; w.rc[d][1] = v.y; w.rc[d][2] = v.z; w.rc[d][3] = v.w;
+  if (EXTRA) { w.pm[d][0] = a.x; w.pm[d][1] = a.y; w.pm[d][2] = a.z; w.pm[d][3] = a.w; }
 }
 
-// per-lane static data of one tile: the lane's state, its arc range and its first
-// kUnroll arc records.  Nothing here depends on DP values, so a tile's TileRegs are
-// fetched from the ring while the previous tile is being computed.
-struct TileRegs {
-  uint32_t rc[kUnroll];
-  uint32_t sid;
-  int a0, a1;  // this lane's arcs: a0, a0 + k, ... < a1 (both 0 for an idle lane)
-};
-
-__device__ __forceinline__ void tile_fetch(const uint32_t *ring, const StepHdr &h, int base, int lane,
-                                           TileRegs &tr) {
-  const int k = 1 << h.kl;
-  const int i = base + (lane >> h.kl);
-  const int r = lane & (k - 1);
-  const uint32_t w0 = ring[(h.st + i) & kRingMask], w1 = ring[(h.st + i + 1) & kRingMask];
-  const bool act = i < h.ns;
-  tr.sid = w0 & 0xffffu;
-  tr.a0 = act ? (int)(w0 >> 16) + r : 0;
-  tr.a1 = act ? (int)(w1 >> 16) : 0;
+// per-arc extras of the tile in register set d (its arc ids have arrived): issued two
+// tiles before they are needed
+template <int U>
+__device__ __forceinline__ void extras_load(const Extra ex, RawTiles &w, int d) {
 #pragma unroll
-  for (int j = 0; j < kUnroll; ++j) {
-    const int a = tr.a0 + j * k;
-    const uint32_t v = ring[(h.rec + a) & kRingMask];  // always a valid LDS address
-    tr.rc[j] = (a < tr.a1) ? v : 0u;
+  for (int j = 0; j < U; ++j) {
+    const int arc = w.pm[d][j];
+    w.xa[d][j] = (arc >= 0 && ex.arc_w) ? ex.arc_w[arc] : 0.0f;
+    w.xb[d][j] = (arc >= 0 && ex.arc_scores) ? ex.arc_scores[arc] : 0.0f;
   }
 }
 
-// One sum-product sweep over one direction's stream, run by W waves (index w) of the
-// workgroup.  With W > 1 the waves meet at one barrier per step and every wave of the
-// workgroup must call lds_barrier() exactly n_barriers + 1 times; with W == 1 a sweep
-// is a single wave, its LDS accesses are ordered, and there is no barrier at all.
-// Software pipeline, per tile: gathers of this tile (theta, alpha/beta) are issued
-// first, then the static reads of the wave's next tile; the sum, the cross-lane
-// reduce and the LDS write of this tile run while those are in flight.
-template <int W>
-__device__ __forceinline__ void ring_sweep(const uint32_t *g, int words, uint32_t *ring_lds, int my_steps,
-                                           int n_barriers, float2 *val, const float2 *th, const Extra ex,
-                                           const int32_t *__restrict__ perm, int w, int lane) {
-  Ring<W> rg;
-  ring_start(rg, ring_lds, g, words, w, lane);
-  if (W > 1) lds_barrier();
-  const uint32_t *ring = ring_lds;
-  const bool has_extra = ex.any();
-  const bool dbg_on = (blockIdx.x == 7);
-  const int dbg_base = (int)(threadIdx.x >> 6) * 512;
-  StepHdr H0 = make_hdr(0, 0, 0, 0), H1 = H0;
-  if (my_steps > 0)
-    H0 = make_hdr(0, __builtin_amdgcn_readfirstlane(ring[0]), __builtin_amdgcn_readfirstlane(ring[1]), 0);
-  if (my_steps > 1)
-    H1 = make_hdr(H0.next_off, __builtin_amdgcn_readfirstlane(ring[H0.next_off & kRingMask]),
-                  __builtin_amdgcn_readfirstlane(ring[(H0.next_off + 1) & kRingMask]), H0.na);
-  TileRegs cur;
-  bool have = false;
-  if (my_steps > 0 && w * (64 >> H0.kl) < H0.ns) {
-    tile_fetch(ring, H0, w * (64 >> H0.kl), lane, cur);
-    have = true;
-  }
-  for (int t = 0; t < n_barriers; ++t) {
-    if (t < my_steps) {
-      STAMP(0);
-      ring_advance(rg, H0.off, lane);
-      // header of step t+2 (static data that has already landed)
-      const bool v1 = t + 1 < my_steps, v2 = t + 2 < my_steps;
-      const uint32_t f0 = ring[H1.next_off & kRingMask], f1 = ring[(H1.next_off + 1) & kRingMask];
-      const int spw = 64 >> H0.kl;
-      const int k = 1 << H0.kl;
-      for (int base = w * spw; base < H0.ns; base += W * spw) {
-        if (!have) tile_fetch(ring, H0, base, lane, cur);
-        STAMP(1);
-        // --- A: gathers of this tile
-        float2 tw[kUnroll], vv[kUnroll];
+// decoder wave, part 1 (kernel entry, before anything else): the first loads need
+// nothing from LDS, so they are in flight while the workgroup initialises
+template <bool EXTRA>
+__device__ __forceinline__ void decoder_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, int lane,
+                                              RawTiles &w) {
 #pragma unroll
-        for (int j = 0; j < kUnroll; ++j) {
-          tw[j] = th[cur.rc[j] >> 16];
-          vv[j] = val[cur.rc[j] & 0xffffu];
-        }
-        // --- B: static data of this wave's next tile (same step, else the next step)
-        const int nbase = base + W * spw;
-        const bool same = nbase < H0.ns;
-        const int nb1 = w * (64 >> H1.kl);
-        const bool hv = same || (v1 && nb1 < H1.ns);
-        const StepHdr Hn = same ? H0 : (hv ? H1 : H0);
-        const int nb = same ? nbase : (hv ? nb1 : base);
-        TileRegs nxt;
-        tile_fetch(ring, Hn, nb, lane, nxt);
-        STAMP(2);
-        // --- C: this tile's sum with one shared exponent
-        float mt[kUnroll];
-        int et[kUnroll];
-#pragma unroll
-        for (int j = 0; j < kUnroll; ++j) {
-          const bool ok = cur.a0 + j * k < cur.a1;
-          float mw = tw[j].x;
-          int ew = __float_as_int(tw[j].y);
-          if (has_extra) {
-            const int a = ok ? cur.a0 + j * k : 0;
-            ME x = exp_split(ex.at(perm[H0.arc_base + a]));
-            mw *= x.m;
-            ew += x.e;
-          }
-          mt[j] = ok ? mw * vv[j].x : 0.0f;
-          et[j] = ok ? ew + __float_as_int(vv[j].y) : kEZero;
-        }
-        int E = max(max(et[0], et[1]), max(et[2], et[3]));
-        float M = (ldexpf(mt[0], et[0] - E) + ldexpf(mt[1], et[1] - E)) +
-                  (ldexpf(mt[2], et[2] - E) + ldexpf(mt[3], et[3] - E));
-        STAMP(3);
-        // --- E: lanes with more than kUnroll arcs (the packer avoids this when it can)
-        if (__any(cur.a0 + kUnroll * k < cur.a1)) {
-          for (int a = cur.a0 + kUnroll * k; a < cur.a1; a += k) {
-            const uint32_t rc = ring[(H0.rec + a) & kRingMask];
-            const float2 t2 = th[rc >> 16], v2f = val[rc & 0xffffu];
-            float mw = t2.x;
-            int ew = __float_as_int(t2.y);
-            if (has_extra) {
-              ME x = exp_split(ex.at(perm[H0.arc_base + a]));
-              mw *= x.m;
-              ew += x.e;
-            }
-            me_acc(M, E, mw * v2f.x, ew + __float_as_int(v2f.y));
-          }
-        }
-        STAMP(4);
-        // --- F: reduce over the state's lanes, normalise, store
-        switch (H0.kl) {
-          case 0: group_reduce<0>(M, E); break;
-          case 1: group_reduce<1>(M, E); break;
-          case 2: group_reduce<2>(M, E); break;
-          case 3: group_reduce<3>(M, E); break;
-          case 4: group_reduce<4>(M, E); break;
-          case 5: group_reduce<5>(M, E); break;
-          default: group_reduce<6>(M, E); break;
-        }
-        if ((lane & (k - 1)) == 0 && base + (lane >> H0.kl) < H0.ns) {
-          if (H0.accum) {
-            const float2 old = val[cur.sid];
-            me_acc(M, E, old.x, __float_as_int(old.y));
-          }
-          val[cur.sid] = me_pack(M, E);
-        }
-        STAMP(5);
-        cur = nxt;
-        have = hv;
-      }
-      // rotate the headers
-      H0 = H1;
-      if (v2) H1 = make_hdr(H1.next_off, __builtin_amdgcn_readfirstlane(f0), __builtin_amdgcn_readfirstlane(f1),
-                            H1.arc_base + H1.na);
+  for (int d = 0; d < kLoadAhead; ++d) {
+    if (d < n_tiles) {
+      if (U == 4) raw_load<4, EXTRA>(g, perm, d, lane, w, d);
+      else if (U == 2) raw_load<2, EXTRA>(g, perm, d, lane, w, d);
+      else raw_load<1, EXTRA>(g, perm, d, lane, w, d);
     }
-    if (W > 1) lds_barrier();
-    STAMP(6);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight
+}
+
+// decoder wave, part 2: decodes the tile program g into the ring
+template <int U, bool EXTRA>
+__device__ __forceinline__ void tile_decoder(RawTiles &w, const uint32_t *g, const int32_t *perm, int n_tiles,
+                                             uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
+                                             const float2 *th_, const Extra ex, int lane) {
+  constexpr int D = kLoadAhead;
+  constexpr int SW = 64 * (1 + 3 * U);
+  const lds_v2f *th = (const lds_v2f *)th_;
+  const uint32_t val_base = lds_addr(val);
+  const uint32_t ring_base = lds_addr(ring);
+  int slot = 0, freed = 0;
+  unsigned long long d_begin, d_end, dw0, dw1, dwaited = 0, dpolls = 0; TSTAMP(d_begin);
+  if (EXTRA) {
+    if (n_tiles > 0) extras_load<U>(ex, w, 0);
+    if (n_tiles > 1) extras_load<U>(ex, w, 1);
+  }
+  for (int t0 = 0; t0 < n_tiles; t0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int t = t0 + d;
+      if (t >= n_tiles) break;
+      if (EXTRA && t + 2 < n_tiles) extras_load<U>(ex, w, (d + 2) % D);
+      // --- decode
+      const uint32_t ctl = w.ctl[d];
+      const uint32_t w0 = (val_base + ((ctl & 0x1fffu) << 3)) | ((ctl & 0x00070000u) << 4) |
+                          ((ctl & 0x00f00000u) << 3) | ((ctl & (1u << 13)) << 18) | ((ctl & (1u << 14)) << 16);
+      uint32_t oa[U];
+      v2f tw[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t rc = w.rc[d][j];
+        tw[j] = th[rc >> 16];
+        oa[j] = val_base + ((rc & 0xffffu) << 3);
+      }
+      if (EXTRA) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (w.pm[d][j] >= 0) {
+            const ME x = exp_split(w.xa[d][j] + w.xb[d][j]);
+            tw[j].x *= x.m;
+            tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
+          }
+        }
+      }
+      // --- the slot must be free: tile t - R consumed
+      if (__builtin_expect(t - freed >= R, 0)) {
+        TSTAMP(dw0);
+        while (t - freed >= R) {
+          freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
+          ++dpolls;
+          if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
+        }
+        TSTAMP(dw1); dwaited += dw1 - dw0;
+      }
+      asm volatile("" ::: "memory");
+      const uint32_t sb = ring_base + (uint32_t)slot * (SW * 4);
+      *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
+      if (U == 4) {
+        *(lds_v4u *)(uintptr_t)(sb + 256 + lane * 16) = v4u{oa[0], oa[1 % U], oa[2 % U], oa[3 % U]};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{tw[2 % U].x, tw[2 % U].y, tw[3 % U].x, tw[3 % U].y};
+      } else if (U == 2) {
+        *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+      } else {
+        *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
+        *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = tw[0];
+      }
+      // --- refill this register set, publish
+      if (t + D < n_tiles) raw_load<U, EXTRA>(g, perm, t + D, lane, w, d);
+      asm volatile("" ::: "memory");
+      lds_flag_store(land, t + 1);
+      slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+  }
+  TSTAMP(d_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = d_end - d_begin; o[1] = dwaited; o[2] = dpolls; o[3] = n_tiles; }
+}
+
+// decoded tile in the sweep wave's registers
+template <int U>
+struct TileDec {
+  uint32_t w0;
+  uint32_t opa[U];
+  v2f tw[U];
+};
+
+template <int U>
+__device__ __forceinline__ void dec_fetch(uint32_t ring_base, int slot, int lane, TileDec<U> &d) {
+  constexpr int SW = 64 * (1 + 3 * U);
+  const uint32_t sb = ring_base + (uint32_t)slot * (SW * 4);
+  d.w0 = *(const lds_u32 *)(uintptr_t)(sb + lane * 4);
+  if (U == 4) {
+    const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 256 + lane * 16);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16);
+    const v4f q = *(const lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y; d.opa[2 % U] = a.z; d.opa[3 % U] = a.w;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w}; d.tw[2 % U] = v2f{q.x, q.y}; d.tw[3 % U] = v2f{q.z, q.w};
+  } else if (U == 2) {
+    const v2u a = *(const lds_v2u *)(uintptr_t)(sb + 256 + lane * 8);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w};
+  } else {
+    d.opa[0] = *(const lds_u32 *)(uintptr_t)(sb + 256 + lane * 4);
+    d.tw[0] = *(const lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8);
+  }
+}
+
+// One sum-product sweep, run by ONE wave over the decoded ring.  The sweep is one
+// dependency chain (gather operands -> sum -> reduce over the state's lanes -> store ->
+// next tile's gathers); an iteration starts with the operand gathers of its tile and
+// fetches the next decoded tile in their shadow.
+template <int U>
+__device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land,
+                                           int lane) {
+  if (n_tiles <= 0) return;
+  const uint32_t ring_base = lds_addr(ring);
+  unsigned long long t_begin, t_end, tw0, tw1, waited = 0, polls = 0; TSTAMP(t_begin);
+  int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
+  auto wait_landed = [&](int need) {
+    if (__builtin_expect(landed < need, 0)) {
+      TSTAMP(tw0);
+      while (landed < need) {
+        landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+        ++polls;
+        if (landed < need) __builtin_amdgcn_s_sleep(1);
+      }
+      TSTAMP(tw1); waited += tw1 - tw0;
+    }
+    asm volatile("" ::: "memory");
+  };
+  const int last = n_tiles - 1;
+  int t1 = 0, slot1 = 0;  // tile fetched next: min(T + 1, last), and its ring slot
+  // iteration T: `cur` = tile T, `nxt` receives tile T+1
+  auto step = [&](int T, const TileDec<U> &cur, TileDec<U> &nxt, bool publish) {
+    // --- operand gathers: the head of the dependency chain
+    v2f vv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)cur.opa[j];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the gathers
+    // --- the next decoded tile (the last iteration re-reads the last tile's slot)
+    if (t1 < last) { ++t1; slot1 = (slot1 + 1 == R) ? 0 : slot1 + 1; }
+    wait_landed(t1 + 1);
+    dec_fetch<U>(ring_base, slot1, lane, nxt);
+    asm volatile("" ::: "memory");
+    // --- everything that only needs the tile's control word is computed in the shadow of
+    // the gathers: which reduce variant (wave-uniform: the tile's largest group has up to
+    // 4 lanes, 8 lanes, or is wider / the tile holds continuation pieces of states with
+    // more than 64 U arcs), the per-lane stage masks, the store address
+    const uint32_t w0 = cur.w0;
+    const int gl = (int)((w0 >> 20) & 7u);
+    const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane(w0);
+    lds_v2f *dst = (lds_v2f *)(uintptr_t)(w0 & 0xfffffu);
+    const bool leader = (int)w0 < 0;
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
+                   m2 = __builtin_amdgcn_ballot_w64(gl > 2);
+    const bool general = (cu & (3u << 25)) != 0;
+    const bool three = (cu & (3u << 23)) == (3u << 23);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // --- this lane's partial sum with one shared exponent
+    auto local_sum = [&](float &M, int &E) {
+      float mt[U];
+      int et[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        mt[j] = cur.tw[j].x * vv[j].x;
+        et[j] = __float_as_int(cur.tw[j].y) + __float_as_int(vv[j].y);
+      }
+      E = et[0];
+#pragma unroll
+      for (int j = 1; j < U; ++j) E = max(E, et[j]);
+      M = ldexpf(mt[0], et[0] - E);
+#pragma unroll
+      for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
+    };
+    // --- reduce over the state's lanes (max of exponents, one rescale, sum), normalise,
+    // store.  The branch is taken before the gathers are back; the two
+    // common variants run their stages under execution masks (seg_reduce_exec).
+    float M;
+    int E;
+    if (__builtin_expect(general, 0)) {
+      local_sum(M, E);
+      seg_reduce_n<6>(M, E, gl);
+      if (leader) {
+        if (w0 & (1u << 30)) {
+          const v2f old = *dst;
+          me_acc(M, E, old.x, __float_as_int(old.y));
+        }
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    } else if (three) {
+      local_sum(M, E);
+      seg_reduce_exec<3>(M, E, m0, m1, m2);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    } else {
+      local_sum(M, E);
+      seg_reduce_exec<2>(M, E, m0, m1, m2);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    }
+    // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
+    if (publish) lds_flag_store(prog, T + 2);
+  };
+  wait_landed(1);
+  TileDec<U> da, db;
+  dec_fetch<U>(ring_base, 0, lane, da);
+  asm volatile("" ::: "memory");
+  // two iterations per trip so that the register roles alternate without copies
+  for (int T = 0; T < n_tiles; T += 2) {
+    step(T, da, db, false);
+    if (T + 1 >= n_tiles) break;
+    step(T + 1, db, da, true);
+  }
+  TSTAMP(t_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = t_end - t_begin; o[1] = waited; o[2] = polls; o[3] = n_tiles; }
+}
+
+// role dispatch: one wave sweeps, another decodes for it
+template <bool EXTRA>
+__device__ __forceinline__ void run_sweep(bool is_consumer, int U, RawTiles &w, const uint32_t *g,
+                                          const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
+                                          float2 *val, const float2 *th, const Extra ex, int lane) {
+  int *prog = flags, *land = flags + 1;
+  if (is_consumer) {
+    if (U == 4) tile_sweep<4>(n_tiles, ring, R, prog, land, lane);
+    else if (U == 2) tile_sweep<2>(n_tiles, ring, R, prog, land, lane);
+    else tile_sweep<1>(n_tiles, ring, R, prog, land, lane);
+  } else {
+    if (U == 4) tile_decoder<4, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 2) tile_decoder<2, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
+    else tile_decoder<1, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
+  }
 }
 
 __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64_t stride, int b,
@@ -400,31 +585,59 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
     ME x = exp_split(t[l]);
     th[l] = make_float2(x.m, __int_as_float(x.e));
   }
+  if (tid == 0) th[V] = make_float2(0.0f, __int_as_float(kEZero));  // the null label of empty slots
 }
 
+// ------------------------------------------------------------------ LDS layout
+// [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V + null label)]
+// [label histogram: v4 float][ring 0: R decoded tiles][ring 1: R decoded tiles][4 flag words]  (16-B aligned)
+struct LdsPlan {
+  int rows2, v2, v4;
+  __host__ __device__ LdsPlan(int max_rows, int vocab)
+      : rows2((max_rows + 1) & ~1), v2((vocab + 2) & ~1), v4((vocab + 3) & ~3) {}
+  __host__ __device__ int64_t fb_bytes(int R) const {
+    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)R * kSlotWords * 4 + 16;
+  }
+  __host__ __device__ int64_t bwd_bytes(int R) const {
+    return ((int64_t)rows2 + v2) * 8 + (int64_t)R * kSlotWords * 4 + 16;
+  }
+};
+
+// Block size: wave 0 runs the beta sweep, wave 1 the alpha sweep; every wave helps with
+// the initialisation, the row outputs and the posterior pass.  With at most one lattice
+// per CU those phases are latency-bound and get 16 waves; with several lattices per CU the
+// co-resident workgroups hide each other's latencies and 4 waves are cheaper.
+
 // ------------------------------------------------------------------ backward only
-// W waves sweep the by-source stream from the sink (block = max(W, 2) * 64 threads...
-// exactly W * 64 threads).
-template <int W>
-__global__ __launch_bounds__(W * 64) void k_backward(nfst_batch lat, nfst_scores sc, float *logbeta,
-                                                     double *logz64, float *logz32, float2 *beta_me) {
+// Wave 0 sweeps the by-source program from the sink; the other waves help with the
+// initialisation and the outputs.
+template <int NT, bool EXTRA>
+__global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, float *logbeta,
+                                                 double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = W * 64;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
-  const int rows2 = (lat.max_rows + 1) & ~1;
+  const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *beta = lds;
-  float2 *th = lds + rows2;
-  uint32_t *ring_lds = (uint32_t *)(th + ((lat.vocab + 1) & ~1));
+  float2 *th = lds + plan.rows2;
+  uint32_t *ring = (uint32_t *)(th + plan.v2);
+  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RawTiles raw;
+  if (wv == 1)
+    decoder_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, lane, raw);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
-  if (tid == 0) beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+  int *flags = (int *)(ring + (size_t)R * kSlotWords);
+  if (tid == 0) {
+    beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+    flags[0] = 0; flags[1] = 0;
+  }
   __syncthreads();
-  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, m.bwd_steps, beta, th, ex,
-                lat.bwd_perm + m.dp_off, w, lane);
+  if (wv < 2)  // wave 0 sweeps, wave 1 decodes the tile program into its ring
+    run_sweep<EXTRA>(wv == 0, m.bwd_u, raw, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
+              m.bwd_tiles, ring, R, flags, beta, th, ex, lane);
   __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -438,15 +651,6 @@ __global__ __launch_bounds__(W * 64) void k_backward(nfst_batch lat, nfst_scores
 }
 
 // ------------------------------------------------------------------ forward-backward
-// Waves [0, W) run the beta sweep and waves [W, 2W) the alpha sweep, concurrently;
-// then every wave of the block streams the canonical arcs once for the posteriors.
-// W = 1: 256-thread block, the two sweeps are single waves that never synchronise
-// (the other two waves wait at the barrier before the posterior pass).
-template <int W>
-struct FbGeom {
-  static constexpr int kThreads = (2 * W * 64 < 256) ? 256 : 2 * W * 64;
-};
-
 __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv, const float2 tw, float rz,
                                                int ez, bool has_extra, const Extra &ex, int a) {
   float mw = tw.x;
@@ -461,22 +665,33 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
   return ldexpf(mm, max(ee, -300));
 }
 
-template <int W>
-__global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
-    nfst_batch lat, nfst_scores sc, float *__restrict__ logalpha, float *__restrict__ logbeta,
+// Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
+// synchronisation between them, fed by waves 2 and 3; after the one barrier that
+// follows every wave of the block streams canonical arcs for the posteriors.
+template <int NT, bool EXTRA>
+__global__ __launch_bounds__(NT) void k_forward_backward(
+    nfst_batch lat, nfst_scores sc, int R, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
-  constexpr int NT = FbGeom<W>::kThreads;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
-  const int rows2 = (lat.max_rows + 1) & ~1;
-  const int v4 = (lat.vocab + 3) & ~3;
+  const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *alpha = lds;
-  float2 *beta = lds + rows2;
-  float2 *th = lds + 2 * rows2;
-  float *gth = (float *)(th + v4);             // [V] label histogram (only if grad_theta)
-  uint32_t *ring_lds = (uint32_t *)(gth + v4);  // two 16 KiB rings: beta stream, alpha stream
+  float2 *beta = lds + plan.rows2;
+  float2 *th = lds + 2 * plan.rows2;
+  float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
+  uint32_t *ring = (uint32_t *)(gth + plan.v4);
+  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
+  constexpr bool has_extra = EXTRA;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool bwd_side = (wv == 0 || wv == 2);  // waves 0 / 2: beta sweep and its decoder; 1 / 3: alpha
+  const uint32_t *my_prog = bwd_side ? lat.bwd_stream + m.bwd_off : lat.fwd_stream + m.fwd_off;
+  const int32_t *my_perm = bwd_side ? lat.bwd_perm + m.bwd_slot_off : lat.fwd_perm + m.fwd_slot_off;
+  const int my_tiles = bwd_side ? m.bwd_tiles : m.fwd_tiles;
+  const int my_u = bwd_side ? m.bwd_u : m.fwd_u;
+  RawTiles raw;
+  if (wv == 2 || wv == 3) decoder_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, lane, raw);
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -484,21 +699,43 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   __syncthreads();
+  int *flags = (int *)(ring + 2 * (size_t)R * kSlotWords);
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     alpha[0] = make_float2(0.5f, __int_as_float(1));
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
   }
   __syncthreads();
-  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int all_steps = max(m.fwd_steps, m.bwd_steps);
-  if (wv < W) {
-    ring_sweep<W>(lat.bwd_stream + m.bwd_off, m.bwd_words, ring_lds, m.bwd_steps, all_steps, beta, th, ex,
-                  lat.bwd_perm + m.dp_off, wv, lane);
-  } else if (wv < 2 * W) {
-    ring_sweep<W>(lat.fwd_stream + m.fwd_off, m.fwd_words, ring_lds + kRingWords, m.fwd_steps, all_steps,
-                  alpha, th, ex, lat.fwd_perm + m.dp_off, wv - W, lane);
+  const bool want_post = posterior != nullptr || grad_theta != nullptr;
+  const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
+  // the posterior pass works on groups of 4 arcs (16-byte loads / stores) over the
+  // aligned interior [v_begin, v_end) of the lattice's canonical arc range
+  const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
+  // The waves beyond the first four have nothing to do during the sweeps: they fetch
+  // their first kPre arc groups into registers now, so that after the sweeps the
+  // posterior pass starts on data that is already there.
+  constexpr int kSweepThreads = 256;
+  constexpr int kHelpers = NT - kSweepThreads;
+  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice (fewer with per-arc extras: the decoder
+  // waves need the registers)
+  constexpr int kPre = (kHelpers > 0) ? (EXTRA ? 2 : 7) : 0;
+  // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
+  uint4 psd[kPre > 0 ? kPre : 1];
+  uint2 plb[kPre > 0 ? kPre : 1];
+  if (kPre > 0 && tid >= kSweepThreads && want_post) {
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
+      if (a < v_end) {
+        psd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
+        plb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
+      }
+    }
   }
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode their tile programs
+  if (wv < 4)
+    run_sweep<EXTRA>(wv < 2, my_u, raw, my_prog, my_perm, my_tiles, bwd_side ? ring : ring + (size_t)R * kSlotWords,
+              R, bwd_side ? flags : flags + 2, bwd_side ? beta : alpha, th, ex, lane);
   __syncthreads();
   const float2 zme = beta[0];
   if (tid == 0) {
@@ -506,130 +743,147 @@ __global__ __launch_bounds__(FbGeom<W>::kThreads) void k_forward_backward(
     if (logz64) logz64[b] = z;
     if (logz32) logz32[b] = (float)z;
   }
-  for (int i = tid; i < m.n_rows; i += NT) {
-    if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
-    if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
-    if (beta_me) beta_me[m.row_off + i] = beta[i];
-  }
-  if (posterior || grad_theta) {
-    const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
-    const int ez = __float_as_int(zme.y);
-    const bool has_extra = ex.any();
-    const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
-    // 4 arcs per lane and iteration with 16-byte loads/stores on the aligned interior
-    const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
-    for (int a = v_begin + tid * 4; a < v_end; a += NT * 4) {
-      const int4 s4 = *reinterpret_cast<const int4 *>(lat.arc_src + a);
-      const int4 d4 = *reinterpret_cast<const int4 *>(lat.arc_dst + a);
-      const int4 l4 = *reinterpret_cast<const int4 *>(lat.arc_label + a);
-      const int ss[4] = {s4.x, s4.y, s4.z, s4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w},
-                ll[4] = {l4.x, l4.y, l4.z, l4.w};
-      float pp[4];
+  const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
+  const int ez = __float_as_int(zme.y);
+  auto do_group = [&](const uint4 sd, const uint2 lb, int a) {
+    const uint32_t sdv[4] = {sd.x, sd.y, sd.z, sd.w};
+    const int ll[4] = {(int)(lb.x & 0xffffu), (int)(lb.x >> 16), (int)(lb.y & 0xffffu), (int)(lb.y >> 16)};
+    float pp[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pp[q] = (ss[q] != dd[q]) ? arc_posterior(alpha[ss[q]], beta[dd[q]], th[ll[q]], rz, ez, has_extra, ex, a + q)
-                                 : 0.0f;
-        if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
+    for (int q = 0; q < 4; ++q) {
+      const int s0 = (int)(sdv[q] & 0xffffu), d0 = (int)(sdv[q] >> 16);
+      pp[q] = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[ll[q]], rz, ez, has_extra, ex, a + q) : 0.0f;
+      if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
+    }
+    if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  };
+  if (kPre > 0 && tid >= kSweepThreads) {
+    if (want_post) {
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
+        if (a < v_end) do_group(psd[u], plb[u], a);
       }
-      if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    }
+  } else {
+    // the sweep waves (all waves when there are no helpers) write the row outputs
+    constexpr int RT = (kPre > 0) ? kSweepThreads : NT;
+    for (int i = tid; i < m.n_rows; i += RT) {
+      if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
+      if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
+      if (beta_me) beta_me[m.row_off + i] = beta[i];
+    }
+  }
+  if (want_post) {
+    // the arc groups that were not preloaded: kPB groups per iteration, all loads issued
+    // before the first use
+    constexpr int kPB = 4;
+    for (int a0 = v_begin + 4 * (kPre * kHelpers + tid); a0 < v_end; a0 += NT * 4 * kPB) {
+      uint4 sd[kPB];
+      uint2 lb[kPB];
+#pragma unroll
+      for (int u = 0; u < kPB; ++u) {
+        const int a = min(a0 + u * NT * 4, v_end - 4);  // clamped: always a valid group
+        sd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
+        lb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
+      }
+#pragma unroll
+      for (int u = 0; u < kPB; ++u) {
+        const int a = a0 + u * NT * 4;
+        if (a >= v_end) break;
+        do_group(sd[u], lb[u], a);
+      }
     }
     // unaligned head and tail (at most 3 arcs each)
     const int n_head = min(v_begin, a_end) - a_begin;
     const int n_tail = (v_end >= v_begin) ? a_end - v_end : 0;
     if (tid < n_head + n_tail) {
       const int a = tid < n_head ? a_begin + tid : v_end + (tid - n_head);
-      const int s = lat.arc_src[a], d = lat.arc_dst[a], l = lat.arc_label[a];
-      const float p = (s != d) ? arc_posterior(alpha[s], beta[d], th[l], rz, ez, has_extra, ex, a) : 0.0f;
+      const int s0 = lat.arc_src[a], d0 = lat.arc_dst[a], l0 = lat.arc_label[a];
+      const float p = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[l0], rz, ez, has_extra, ex, a) : 0.0f;
       if (posterior) posterior[a] = p;
-      if (grad_theta && p > 0.0f) atomicAdd(&gth[l], p);
+      if (grad_theta && p > 0.0f) atomicAdd(&gth[l0], p);
     }
     if (grad_theta) {
       __syncthreads();
-      float *g = grad_theta + (size_t)b * lat.vocab;
-      for (int l = tid; l < lat.vocab; l += NT) g[l] = gth[l];
+      float *gout = grad_theta + (size_t)b * lat.vocab;
+      for (int l = tid; l < lat.vocab; l += NT) gout[l] = gth[l];
     }
   }
 }
 
 // ------------------------------------------------------------------ Viterbi
-// max-plus sweep over the by-source stream; float32 values, canonical arc back
-// pointers; thread 0 then walks the best path.
-__global__ __launch_bounds__(256) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
-                                                 int32_t *paths, int32_t *path_arcs,
-                                                 int32_t *lengths, int max_len, int pad) {
+// max-plus run of the by-source tile program by one wave (float32 values, canonical
+// arc back pointers in LDS; the program is read straight from global memory -- this
+// kernel is not on the benchmark path), then lane 0 walks the best path.  Ties keep
+// the arc with the smallest canonical id, i.e. the smallest label.
+__device__ __forceinline__ void vit_take(float &bv, int &ba, float ov, int oa) {
+  if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; }
+}
+
+__global__ __launch_bounds__(64) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
+                                                int32_t *paths, int32_t *path_arcs,
+                                                int32_t *lengths, int max_len, int pad) {
   extern __shared__ float2 lds[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, lane = threadIdx.x;
   const Meta m = load_meta(lat.meta, b);
   float *v = (float *)lds;
   int *bp = (int *)(v + lat.max_rows);
-  float *th = (float *)(bp + lat.max_rows);
-  for (int i = tid; i < m.n_rows; i += 256) { v[i] = kNegInf; bp[i] = -1; }
+  for (int i = lane; i < m.n_rows; i += 64) { v[i] = kNegInf; bp[i] = -1; }
+  __syncthreads();
+  if (lane == 0) v[m.sink] = 0.0f;
+  __syncthreads();
   const float *tg = sc.theta + (size_t)sc.theta_stride * b;
-  for (int l = tid; l < lat.vocab; l += 256) th[l] = tg[l];
-  __syncthreads();
-  if (tid == 0) v[m.sink] = 0.0f;
-  __syncthreads();
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
-  const uint32_t *stream = lat.bwd_stream + m.bwd_off;
-  const int32_t *perm = lat.bwd_perm + m.dp_off;
-  int off = 0, arc_base = 0;
-  for (int t = 0; t < m.bwd_steps; ++t) {
-    const uint32_t *step = stream + off;
-    const uint32_t h0 = __builtin_amdgcn_readfirstlane(step[0]);
-    const int na = (int)__builtin_amdgcn_readfirstlane(step[1]);
-    const int ns = (int)(h0 & 0xffffu), kl = (int)((h0 >> 16) & 0xfu);
-    const bool accum = ((h0 >> 20) & 1u) != 0;
-    const uint32_t *st = step + 2, *rec = st + ns + 1;
-    const int spw = 64 >> kl, k = 1 << kl;
-    for (int base = wave * spw; base < ns; base += kViterbiWaves * spw) {
-      const int i = base + (lane >> kl), r = lane & (k - 1);
-      float bv = kNegInf;
-      int ba = 0x7fffffff;
-      uint32_t sid = 0;
-      if (i < ns) {
-        const uint32_t w0 = st[i], w1 = st[i + 1];
-        sid = w0 & 0xffffu;
-        for (int a = (int)(w0 >> 16) + r; a < (int)(w1 >> 16); a += k) {
-          const uint32_t rc = rec[a];
-          const int ca = perm[arc_base + a];
-          float s = th[rc >> 16];
-          if (arc_w) s += arc_w[ca];
-          if (sc.arc_scores) s += sc.arc_scores[ca];
-          const float c = s + v[rc & 0xffffu];
-          if (c > bv) { bv = c; ba = ca; }
-        }
-      }
-      for (int d = 1; d < k; d <<= 1) {
-        const float ov = __shfl_xor(bv, d);
-        const int oa = __shfl_xor(ba, d);
-        if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; }
-      }
-      if (i < ns && r == 0) {
-        if (accum) {
-          const float ov = v[sid];
-          const int oa = bp[sid];
-          if (ov > bv || (ov == bv && oa >= 0 && oa < ba)) { bv = ov; ba = oa; }
-        }
-        v[sid] = bv;
-        bp[sid] = (ba == 0x7fffffff) ? -1 : ba;
-      }
+  const int U = m.bwd_u, ST = 64 * (1 + U);
+  const uint32_t *prog = lat.bwd_stream + m.bwd_off;
+  const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
+  constexpr int kNone = 0x7fffffff;
+  for (int T = 0; T < m.bwd_tiles; ++T) {
+    const uint32_t ctl = prog[(size_t)T * ST + lane];
+    float bv = kNegInf;
+    int ba = kNone;
+    for (int j = 0; j < U; ++j) {
+      const int ca = perm[(size_t)T * 64 * U + lane * U + j];
+      if (ca < 0) continue;
+      const uint32_t rc = prog[(size_t)T * ST + 64 + lane * U + j];
+      float s0 = tg[rc >> 16];
+      if (arc_w) s0 += arc_w[ca];
+      if (sc.arc_scores) s0 += sc.arc_scores[ca];
+      vit_take(bv, ba, s0 + v[rc & 0xffffu], ca);
     }
-    off += 2 + ns + 1 + na;
-    arc_base += na;
-    __syncthreads();
+    const int gl = (int)((ctl >> 16) & 7u);
+    for (int st = 0; st < 6; ++st) {
+      int partner;
+      if (st == 0) partner = lane ^ 1;
+      else if (st == 1) partner = lane ^ 2;
+      else if (st == 2) partner = (lane & ~7) | (7 - (lane & 7));
+      else if (st == 3) partner = (lane & ~15) | (15 - (lane & 15));
+      else partner = lane ^ (1 << st);
+      const float ov = __shfl(bv, partner);
+      const int oa = __shfl(ba, partner);
+      if (gl > st) vit_take(bv, ba, ov, oa);
+    }
+    if (ctl & (1u << 13)) {
+      const uint32_t sid = ctl & 0x1fffu;
+      if ((ctl & (1u << 14)) && bp[sid] >= 0) vit_take(bv, ba, v[sid], bp[sid]);
+      v[sid] = bv;
+      bp[sid] = (ba == kNone) ? -1 : ba;
+    }
+    __syncthreads();  // single wave: orders the LDS stores before the next tile's loads
   }
-  if (tid == 0) {
+  if (lane == 0) {
     best[b] = v[0];
-    int s = 0, len = 0;
-    while (s != m.sink && len < max_len) {
-      const int a = bp[s];
+    int s0 = 0, len = 0;
+    while (s0 != m.sink && len < max_len) {
+      const int a = bp[s0];
       if (a < 0) break;
       paths[(size_t)b * max_len + len] = lat.arc_label[a];
       if (path_arcs) path_arcs[(size_t)b * max_len + len] = a;
       ++len;
-      s = lat.arc_dst[a];
+      s0 = lat.arc_dst[a];
     }
-    lengths[b] = (s == m.sink) ? len : -1;
+    lengths[b] = (s0 == m.sink) ? len : -1;
     for (int j = len; j < max_len; ++j) {
       paths[(size_t)b * max_len + j] = pad;
       if (path_arcs) path_arcs[(size_t)b * max_len + j] = -1;
@@ -835,10 +1089,133 @@ __device__ __forceinline__ float seq_mask(int v, int t, int prev, int pad, int b
   return mk;
 }
 
+// wave64 all-reduce without LDS traffic: quad permutes and row mirrors (DPP) reduce each
+// row of 16 lanes, v_readlane collects the four row results
+__device__ __forceinline__ float read_lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  return (a + b) + (c + d);
+}
+
+// Streaming version for V % 4 == 0, V <= 1024: every wave keeps RB rows in registers
+// (16-byte loads, RB * NV of them in flight per lane -- the kernel is HBM-bound and would be
+// latency-bound with one row at a time), two-pass softmax per row (max, then sum of exp).
+template <int NV, int RB>
+__global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
+                                                         const int64_t *__restrict__ marks, int T, int V,
+                                                         int pad, int bos, int eos, int max_length,
+                                                         float temp, int normalize, float smoothing,
+                                                         float *out) {
+  __shared__ float part[4];
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t *mk = marks + n * T;
+  const float rtemp = 1.0f / temp;
+  float acc = 0.0f;
+  for (int t0 = wave * RB; t0 < T; t0 += 4 * RB) {
+    float4 v[RB][NV];
+    int lab[RB], prev[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = min(t0 + r, T - 1);  // clamped: rows past the end are loaded but not used
+      const float4 *row = reinterpret_cast<const float4 *>(scores + ((size_t)n * T + t) * V);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const int q = c * 64 + lane;
+        v[r][c] = (4 * q < V) ? row[q] : make_float4(kNegInf, kNegInf, kNegInf, kNegInf);
+      }
+      lab[r] = (int)mk[t];
+      prev[r] = t > 0 ? (int)mk[t - 1] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = t0 + r;
+      if (t >= T) break;
+      float sel;
+      const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
+      const float lraw = scores[((size_t)n * T + t) * V + lab[r]];  // L1/L2 hit: the row was just read
+      const float lx = ((lab[r] == pad ? 0.0f : lraw) + lmsk) / temp + lmsk;
+      sel = lx;
+      if (normalize || smoothing > 0.0f) {
+        // row-level legality (scorers.py:59-83): hoisted out of the per-column loop
+        const bool first = t == 0;
+        const bool ended = !first && (prev[r] == eos || prev[r] == pad);
+        const bool force = !first && max_length >= 0 && t > max_length && !ended;
+        float mx = kNegInf;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          float *e = reinterpret_cast<float *>(&v[r][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int col = (c * 64 + lane) * 4 + k;
+            bool bad = col == bos;
+            bad |= first ? (col == pad) : (ended ? (col != pad) : (col == pad));
+            bad |= force && col != eos;
+            const float x = (col == pad ? 0.0f : e[k]) * rtemp;
+            e[k] = (bad || col >= V) ? kNegInf : x;
+            mx = fmaxf(mx, e[k]);
+          }
+        }
+        float lse = 0.0f;
+        if (normalize) {
+          mx = wave_max(mx);
+          float sm = 0.0f;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);  // masked / padding columns: exp(-inf) = 0
+          }
+          sm = wave_sum(sm);
+          lse = mx + logf(sm);
+          sel = lx - lse;  // an all -inf row gives NaN, like the reference
+        }
+        if (smoothing > 0.0f) {
+          // training: label-smoothed target (scorers.py:1502-1528, 1584-1592): weight 1 - s on
+          // the realised mark, s / (cnt - 1) on every other legal mark, values clamped to +-1e9
+          float sx = 0.0f, cnt = 0.0f;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (e[k] > kNegInf) { sx += e[k]; cnt += 1.0f; }
+          }
+          sx = wave_sum(sx);
+          cnt = wave_sum(cnt);
+          const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
+          float rest = sx - cnt * lse;  // sum of the legal marks' values ...
+          float others = cnt;
+          if (lx > kNegInf) { rest -= sel; others -= 1.0f; }  // ... other than the realised one
+          sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
+        }
+      }
+      acc += sel * (lab[r] != pad ? 1.0f : 0.0f);
+    }
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
 __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const int64_t *marks,
                                                       int T, int V, int pad, int bos, int eos,
                                                       int max_length, float temp, int normalize,
-                                                      float *out) {
+                                                      float smoothing, float *out) {
   __shared__ float part[4];
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -873,6 +1250,25 @@ __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const
       const float msk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
       sel = ((lab == pad ? 0.0f : row[lab]) + msk) / temp + msk;
     }
+    if (smoothing > 0.0f) {
+      // label-smoothed target (scorers.py:1502-1528, 1584-1592)
+      float lse = 0.0f;
+      const float lmsk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
+      const float lx = ((lab == pad ? 0.0f : row[lab]) + lmsk) / temp + lmsk;
+      if (normalize) lse = lx - sel;
+      float sx = 0.0f, cnt = 0.0f;
+      for (int v = lane; v < V; v += 64) {
+        const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
+        const float x = ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+        if (x > kNegInf) { sx += x; cnt += 1.0f; }
+      }
+      sx = wave_sum(sx);
+      cnt = wave_sum(cnt);
+      const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
+      float rest = sx - cnt * lse, others = cnt;
+      if (lx > kNegInf) { rest -= sel; others -= 1.0f; }
+      sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
+    }
     acc += sel * (lab != pad ? 1.0f : 0.0f);
   }
   // every lane of a wave holds the same acc; reduce the 4 waves in a fixed order
@@ -901,11 +1297,9 @@ int check_batch(const nfst_batch *lat) {
   if (!lat || lat->n_lattices <= 0 || lat->vocab <= 0 || lat->max_rows <= 0) return NFST_ERR_ARG;
   if (!lat->meta || !lat->row_ptr || !lat->fwd_stream || !lat->bwd_stream) return NFST_ERR_ARG;
   if (lat->total_arcs > 0 && (!lat->arc_src || !lat->arc_dst || !lat->arc_label)) return NFST_ERR_ARG;
-  if (lat->total_dp_arcs > 0 && (!lat->fwd_perm || !lat->bwd_perm)) return NFST_ERR_ARG;
+  if ((lat->fwd_slots > 0 && !lat->fwd_perm) || (lat->bwd_slots > 0 && !lat->bwd_perm)) return NFST_ERR_ARG;
   if (lat->weighted && !lat->arc_w) return NFST_ERR_ARG;
   if (lat->max_rows > NFST_MAX_ROWS || lat->vocab > NFST_MAX_VOCAB) return NFST_ERR_LIMIT;
-  if (lat->max_step_words <= 0 || lat->max_step_words > NFST_MAX_STEP_WORDS) return NFST_ERR_LIMIT;
-  if (lat->sweep_waves != 1 && lat->sweep_waves != 2 && lat->sweep_waves != 4) return NFST_ERR_ARG;
   if (((uintptr_t)lat->fwd_stream | (uintptr_t)lat->bwd_stream) & 15) return NFST_ERR_ARG;
   return NFST_OK;
 }
@@ -918,13 +1312,26 @@ int hip_status(hipError_t e) { return e == hipSuccess ? NFST_OK : NFST_ERR_HIP; 
 
 constexpr int64_t kMaxLds = 160 * 1024;
 
+// Dynamic LDS above 64 KiB needs a per-kernel opt-in; it is sticky, so it is requested
+// once per kernel and size (hipFuncSetAttribute is slow and not capturable in a graph).
 template <class K>
 int set_lds(K kernel, int64_t bytes) {
   if (bytes > kMaxLds) return NFST_ERR_LIMIT;
-  if (bytes > 64 * 1024)
-    return hip_status(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return NFST_OK;
+  if (bytes <= 64 * 1024) return NFST_OK;
+  static const void *seen_fn[32];
+  static int64_t seen_bytes[32];
+  static int n_seen = 0;
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  for (int i = 0; i < n_seen; ++i)
+    if (seen_fn[i] == fn) {
+      if (seen_bytes[i] >= bytes) return NFST_OK;
+      int rc = hip_status(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      if (rc == NFST_OK) seen_bytes[i] = bytes;
+      return rc;
+    }
+  int rc = hip_status(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (rc == NFST_OK && n_seen < 32) { seen_fn[n_seen] = fn; seen_bytes[n_seen] = bytes; ++n_seen; }
+  return rc;
 }
 
 }  // namespace
@@ -939,8 +1346,34 @@ int nfst_device_available(void) {
 
 int64_t nfst_lds_bytes(const nfst_batch *lat) {
   if (!lat) return NFST_ERR_ARG;
-  const int64_t rows2 = (lat->max_rows + 1) & ~1, v4 = (lat->vocab + 3) & ~3;
-  return (2 * rows2 + v4) * 8 + v4 * 4 + 2 * (int64_t)kRingWords * 4;
+  return LdsPlan(lat->max_rows, lat->vocab).fb_bytes(kMinRing);
+}
+
+// ring slots per sweep: as many as the LDS budget of one workgroup allows (kMinRing .. kMaxRing);
+// with more lattices than CUs two workgroups share a CU's 160 KiB if the lattices are small enough
+static int ring_slots(int64_t fixed_bytes, int n_rings, bool share_cu) {
+  const int64_t slot = (int64_t)kSlotWords * 4 * n_rings;
+  if (share_cu) {
+    const int64_t r = (kMaxLds / 2 - fixed_bytes) / slot;
+    if (r >= kMinRing + 1) return (int)(r > kMaxRing ? kMaxRing : r);
+  }
+  const int64_t r = (kMaxLds - fixed_bytes) / slot;
+  if (r < kMinRing) return 0;
+  return (int)(r > kMaxRing ? kMaxRing : r);
+}
+
+// number of CUs of the current device (cached per process; 256 on MI355X)
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
 }
 
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta, double *logz64,
@@ -948,19 +1381,19 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  const int64_t lds = (((int64_t)lat->max_rows + 1) / 2 * 2 + ((int64_t)lat->vocab + 1) / 2 * 2) * 8 +
-                      (int64_t)kRingWords * 4;
-#define NFST_LAUNCH_BWD(W)                                                                              \
-  {                                                                                                     \
-    if ((rc = set_lds(k_backward<W>, lds))) return rc;                                                  \
-    hipLaunchKernelGGL(k_backward<W>, dim3(lat->n_lattices), dim3(W * 64), (size_t)lds,                 \
-                       (hipStream_t)stream, *lat, *scores, logbeta, logz64, logz32, (float2 *)beta_me); \
+  const LdsPlan plan(lat->max_rows, lat->vocab);
+  const int R = ring_slots(plan.bwd_bytes(0), 1, lat->n_lattices > cu_count());
+  if (R == 0) return NFST_ERR_LIMIT;
+  const int64_t lds = plan.bwd_bytes(R);
+#define NFST_LAUNCH_BWD(NT, EX)                                                                          \
+  {                                                                                                    \
+    if ((rc = set_lds(k_backward<NT, EX>, lds))) return rc;                                            \
+    hipLaunchKernelGGL((k_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,             \
+                       (hipStream_t)stream, *lat, *scores, R, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
-  switch (lat->sweep_waves) {
-    case 1: NFST_LAUNCH_BWD(1) break;
-    case 2: NFST_LAUNCH_BWD(2) break;
-    default: NFST_LAUNCH_BWD(4) break;
-  }
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
+  if (lat->n_lattices <= cu_count()) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
+  else { if (extra) NFST_LAUNCH_BWD(256, true) else NFST_LAUNCH_BWD(256, false) }
 #undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
 }
@@ -972,20 +1405,25 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
-  if (((uintptr_t)lat->arc_src | (uintptr_t)lat->arc_dst | (uintptr_t)lat->arc_label) & 15) return NFST_ERR_ARG;
-  const int64_t lds = nfst_lds_bytes(lat);
-#define NFST_LAUNCH_FB(W)                                                                               \
+  if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
+  const LdsPlan plan(lat->max_rows, lat->vocab);
+  const int R = ring_slots(plan.fb_bytes(0), 2, lat->n_lattices > cu_count());
+  if (R == 0) return NFST_ERR_LIMIT;
+  const int64_t lds = plan.fb_bytes(R);
+#define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
-    if ((rc = set_lds(k_forward_backward<W>, lds))) return rc;                                          \
-    hipLaunchKernelGGL(k_forward_backward<W>, dim3(lat->n_lattices), dim3(FbGeom<W>::kThreads),         \
-                       (size_t)lds, (hipStream_t)stream, *lat, *scores, logalpha, logbeta, logz64,      \
-                       logz32, posterior, grad_theta, (float2 *)beta_me);                               \
+    if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
+    hipLaunchKernelGGL((k_forward_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,      \
+                       (hipStream_t)stream, *lat, *scores, R, logalpha, logbeta, logz64, logz32, posterior, \
+                       grad_theta, (float2 *)beta_me);                                                  \
   }
-  switch (lat->sweep_waves) {
-    case 1: NFST_LAUNCH_FB(1) break;
-    case 2: NFST_LAUNCH_FB(2) break;
-    default: NFST_LAUNCH_FB(4) break;
-  }
+  const int cus = cu_count();
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
+  // (the variants with per-arc extras need ~170 registers: 8 waves per workgroup at most)
+  if (extra) { if (lat->n_lattices <= cus) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(256, true) }
+  else if (lat->n_lattices <= cus) NFST_LAUNCH_FB(1024, false)
+  else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512, false)
+  else NFST_LAUNCH_FB(256, false)
 #undef NFST_LAUNCH_FB
   return hip_status(hipGetLastError());
 }
@@ -996,10 +1434,10 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (!best || !paths || !lengths || max_len <= 0) return NFST_ERR_ARG;
-  const int64_t lds = (int64_t)lat->max_rows * 8 + (int64_t)lat->vocab * 4;
+  const int64_t lds = (int64_t)lat->max_rows * 8;
   if ((rc = set_lds(k_viterbi, lds))) return rc;
-  hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(256), (size_t)lds, (hipStream_t)stream,
-                     *lat, *scores, best, paths, path_arcs, lengths, (int)max_len, (int)pad);
+  hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(64), (size_t)lds, (hipStream_t)stream, *lat,
+                     *scores, best, paths, path_arcs, lengths, (int)max_len, (int)pad);
   return hip_status(hipGetLastError());
 }
 
@@ -1077,12 +1515,22 @@ int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, f
 
 int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int32_t t, int32_t vocab,
                       int32_t pad, int32_t bos, int32_t eos, int32_t max_length, float temp,
-                      int32_t normalize, float *out, void *stream) {
+                      int32_t normalize, float smoothing, float *out, void *stream) {
   if (!scores || !marks || !out || n <= 0 || t <= 0 || vocab <= 0 || !(temp > 0.0f)) return NFST_ERR_ARG;
+  if (!(smoothing >= 0.0f && smoothing < 1.0f)) return NFST_ERR_ARG;  // scorers.py:1514
   if (n > 0x7fffffffll) return NFST_ERR_LIMIT;
-  hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
-                     (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
-                     (int)normalize, out);
+#define NFST_LAUNCH_PLP(NV, RB)                                                                         \
+  hipLaunchKernelGGL((k_path_logprob_v4<NV, RB>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
+                     scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,   \
+                     temp, (int)normalize, smoothing, out)
+  if (vocab % 4 == 0 && vocab <= 256 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(1, 8);
+  else if (vocab % 4 == 0 && vocab <= 512 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(2, 4);
+  else if (vocab % 4 == 0 && vocab <= 1024 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(4, 2);
+  else
+    hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
+                       (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
+                       (int)normalize, smoothing, out);
+#undef NFST_LAUNCH_PLP
   return hip_status(hipGetLastError());
 }
 

@@ -1,19 +1,37 @@
-"""Diagnostic copy of the library with s_memtime stamps in ring_sweep (never shipped)."""
-import subprocess
+"""Diagnostic copy of the library with s_memtime stamps in tile_sweep (never shipped).
+usage: prof_patch.py POINT   (POINT in B C D N: where the second stamp goes; N = only the loop-top stamp)"""
+import subprocess, sys
+point = sys.argv[1]
 src = open('nfst_amd/csrc/kernels.hip').read()
-src = src.replace('namespace {\n\nconstexpr int kEZero', '__device__ unsigned long long g_dbg[8192];\nextern "C" int nfst_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long)*8192); }\nnamespace {\n#define STAMP(slot) do { if (dbg_on && t >= 20 && t < 52) { unsigned long long c_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory"); if (lane == 0) g_dbg[dbg_base + (t-20)*8 + (slot)] = c_; } } while(0)\n\nconstexpr int kEZero',1)
-def rep(a,b):
+hdr = r'''__device__ unsigned long long g_dbg[8192];
+extern "C" int nfst_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long)*8192); }
+namespace {
+#define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+
+constexpr int kEZero'''
+src = src.replace('namespace {\n\nconstexpr int kEZero', hdr, 1)
+def rep(a, b):
     global src
     assert a in src, a
-    src = src.replace(a,b,1)
-rep('  const uint32_t *ring = ring_lds;\n  const bool has_extra = ex.any();','  const uint32_t *ring = ring_lds;\n  const bool has_extra = ex.any();\n  const bool dbg_on = (blockIdx.x == 7);\n  const int dbg_base = (int)(threadIdx.x >> 6) * 512;')
-rep('      ring_advance(rg, H0.off, lane);','      STAMP(0);\n      ring_advance(rg, H0.off, lane);')
-rep('        // --- A: gathers of this tile','        STAMP(1);\n        // --- A: gathers of this tile')
-rep('        // --- C: this tile\'s sum with one shared exponent','        STAMP(2);\n        // --- C: this tile\'s sum with one shared exponent')
-rep('        // --- E: lanes with more than kUnroll arcs','        STAMP(3);\n        // --- E: lanes with more than kUnroll arcs')
-rep('        // --- F: reduce over the state\'s lanes, normalise, store','        STAMP(4);\n        // --- F: reduce over the state\'s lanes, normalise, store')
-rep('        cur = nxt;\n        have = hv;','        STAMP(5);\n        cur = nxt;\n        have = hv;')
-rep('    if (W > 1) lds_barrier();\n  }\n  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight','    if (W > 1) lds_barrier();\n    STAMP(6);\n  }\n  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring stays in flight')
-open('scratch/kernels_prof.hip','w').write(src)
-subprocess.check_call(['/opt/rocm/bin/hipcc','-O3','--offload-arch=gfx950','-fPIC','-shared','-pthread','-std=c++17','-Iinclude','nfst_amd/csrc/pack.cpp','scratch/kernels_prof.hip','-o','scratch/libnfst_prof.so'])
-print("built")
+    src = src.replace(a, b, 1)
+rep('  int landed = 0;  // wave-uniform copy of the decoder\'s counter',
+    '  unsigned long long tA = 0, tX = 0, accX = 0, accI = 0, tPrev = 0, t_begin, polls = 0; TSTAMP(t_begin);\n  int landed = 0;  // wave-uniform copy of the decoder\'s counter')
+rep('      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));\n      if (landed < need) __builtin_amdgcn_s_sleep(1);\n    }\n    asm volatile("" ::: "memory");\n  };\n  const int last',
+    '      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));\n      ++polls;\n      if (landed < need) __builtin_amdgcn_s_sleep(1);\n    }\n    asm volatile("" ::: "memory");\n  };\n  const int last')
+rep('    // --- operand gathers: the head of the dependency chain',
+    '    TSTAMP(tA); if (T > 0) accI += tA - tPrev; tPrev = tA;')
+pts = {
+ 'B': ('    // --- reduce over the state\'s lanes, normalise, store.  The tile\'s largest group', None),
+ 'C': ('    // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above', None),
+}
+if point == 'B':
+    rep("    const uint32_t w0 = cur.w0;\n    const int gl", "    asm volatile(\"\" :: \"v\"(M), \"v\"(E));\n    TSTAMP(tX); accX += tX - tA;\n    const uint32_t w0 = cur.w0;\n    const int gl")
+elif point == 'G':  # right after the gathers have returned
+    rep("    // --- this lane's partial sum with one shared exponent", "    asm volatile(\"\" :: \"v\"(vv[0]), \"v\"(vv[U-1]));\n    TSTAMP(tX); accX += tX - tA;")
+elif point == 'D':
+    rep("    if (publish) lds_flag_store(prog, T + 2);\n  };", "    TSTAMP(tX); accX += tX - tA;\n    if (publish) lds_flag_store(prog, T + 2);\n  };")
+rep('    step(T + 1, db, da, true);\n  }\n', '    step(T + 1, db, da, true);\n  }\n  { unsigned long long t_end; TSTAMP(t_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = t_end - t_begin; o[1] = accI; o[2] = accX; o[3] = polls; o[4] = n_tiles; } }\n')
+open('scratch/kernels_prof.hip', 'w').write(src)
+subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-shared', '-pthread', '-std=c++17', '-Wno-inline-asm',
+                       '-Iinclude', 'nfst_amd/csrc/pack.cpp', 'scratch/kernels_prof.hip', '-o', 'scratch/libnfst_prof_%s.so' % point])
+print("built", point)
