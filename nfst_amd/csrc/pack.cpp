@@ -34,7 +34,7 @@ struct Lat {
   std::vector<int32_t> row_ptr;  // n_rows + 1, relative
   std::vector<uint32_t> fwd, bwd;
   std::vector<int32_t> fwd_perm, bwd_perm;  // per tile slot: relative canonical arc id or -1
-  int fwd_tiles = 0, bwd_tiles = 0, fwd_u = 4, bwd_u = 4, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
+  int fwd_tiles = 0, bwd_tiles = 0, fwd_u = 4, bwd_u = 4, fwd_wide = 0, bwd_wide = 0, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
   int err = NFST_OK;
 };
 
@@ -44,68 +44,94 @@ inline int ceil_log2(int x) { int g = 0; while ((1 << g) < x) ++g; return g; }
 // wave-wide unit of work: 64 control words + 64*U arc records (U = slots per lane).
 // A state with d arcs takes 2^g lanes, g = ceil(log2(ceil(d/U))), at a lane offset
 // that is a multiple of 2^g; lane r of the group owns arcs [r*U, r*U+U).  Tiles
-// never mix levels, so every record's operand was produced by an earlier tile.  A
-// state with more than 64*U arcs is cut into pieces; the later pieces carry the
-// "accumulate" flag and follow in later tiles.
+// never mix levels, so every record's operand was produced by an earlier tile.
+//
+// A state whose arcs do not fit the largest group (2^max_g lanes) is cut into pieces
+// that go into successive tiles: every continuation piece starts with a CARRY record
+// (operand = the state itself, label = vocab + 1, weight one), so its sum includes what
+// the earlier pieces stored and the piece simply overwrites the state's value.  Its
+// leader lane also carries the "accumulate" flag (the max-plus kernel keeps the earlier
+// back pointer when the carry wins).  max_g = 3 ("narrow": groups of up to 8 lanes, the
+// sweep needs no cross-row reduction stage) or 6 ("wide": up to the whole wave).
 struct Piece { int32_t state; int32_t begin, end; bool accum; };  // arcs [begin,end) of the state's list
 
+struct TileCount { int tiles = 0, wide = 0; };  // wide: tiles whose largest group exceeds 8 lanes
+
 template <class ArcsOf, class Other>
-void emit_level(const std::vector<int32_t> &states, int U, uint32_t null_label, ArcsOf arcs_of, Other other,
+void emit_level(const std::vector<int32_t> &states, int U, int max_g, uint32_t null_label, ArcsOf arcs_of, Other other,
                 const std::vector<int32_t> &list, const std::vector<int32_t> &label,
-                std::vector<uint32_t> *stream, std::vector<int32_t> *perm, int &n_tiles) {
-  const int cap = 64 * U;
-  std::vector<Piece> head, tail;  // full-wave pieces first, the rest after them
+                std::vector<uint32_t> *stream, std::vector<int32_t> *perm, TileCount &count) {
+  const int cap = (1 << max_g) * U;
+  const uint32_t null_rec = null_label << 16, unit_label = null_label + 1;
+  // pass k holds the k-th piece of every state of the level
+  std::vector<std::vector<Piece>> passes(1);
   for (int32_t s : states) {
     auto r = arcs_of(s);
     int b = r.first;
-    bool first = true;
-    while (r.second - b > cap) { head.push_back({s, b, b + cap, !first}); b += cap; first = false; }
-    tail.push_back({s, b, r.second, !first});
+    size_t k = 0;
+    for (;;) {
+      const int room = (k == 0) ? cap : cap - 1;  // a continuation piece spends one slot on the carry
+      const int e = std::min(r.second, b + room);
+      if (passes.size() <= k) passes.emplace_back();
+      passes[k].push_back({s, b, e, k > 0});
+      b = e;
+      ++k;
+      if (b >= r.second) break;
+    }
   }
-  auto lanes_of = [&](const Piece &p) { return std::max(1, (p.end - p.begin + U - 1) / U); };
-  std::stable_sort(tail.begin(), tail.end(), [&](const Piece &a, const Piece &b) {
-    return ceil_log2(lanes_of(a)) > ceil_log2(lanes_of(b));
-  });
-  head.insert(head.end(), tail.begin(), tail.end());
-  size_t i = 0;
-  const uint32_t null_rec = null_label << 16;
-  while (i < head.size()) {
-    uint32_t ctl[64];
-    std::vector<uint32_t> rec((size_t)64 * U, null_rec);
-    std::vector<int32_t> pm((size_t)64 * U, -1);
-    for (int l = 0; l < 64; ++l) ctl[l] = 0;
-    int lane = 0, gmax = 0;
-    bool any_accum = false;
-    while (i < head.size()) {
-      const Piece &p = head[i];
-      const int g = ceil_log2(lanes_of(p));
-      const int size = 1 << g;
-      if (lane + size > 64) break;
-      gmax = std::max(gmax, g);
-      any_accum = any_accum || p.accum;
-      for (int r = 0; r < size; ++r) {
-        uint32_t c = (uint32_t)p.state | ((uint32_t)g << 16);
-        if (r == 0) c |= (1u << 13) | (p.accum ? (1u << 14) : 0u);
-        ctl[lane + r] = c;
-        for (int j = 0; j < U; ++j) {
-          const int a = p.begin + r * U + j;
-          if (a < p.end) {
-            const int32_t arc = list[a];
-            rec[(size_t)(lane + r) * U + j] = (uint32_t)other(arc) | ((uint32_t)label[arc] << 16);
-            pm[(size_t)(lane + r) * U + j] = arc;
+  auto lanes_of = [&](const Piece &p) { return std::max(1, (p.end - p.begin + (p.accum ? 1 : 0) + U - 1) / U); };
+  for (auto &pieces : passes) {
+    std::stable_sort(pieces.begin(), pieces.end(), [&](const Piece &a, const Piece &b) {
+      return ceil_log2(lanes_of(a)) > ceil_log2(lanes_of(b));
+    });
+    size_t i = 0;
+    while (i < pieces.size()) {
+      uint32_t ctl[64];
+      std::vector<uint32_t> rec;
+      std::vector<int32_t> pm;
+      if (stream) { rec.assign((size_t)64 * U, null_rec); pm.assign((size_t)64 * U, -1); }
+      for (int l = 0; l < 64; ++l) ctl[l] = 0;
+      int lane = 0, gmax = 0;
+      bool any_accum = false;
+      while (i < pieces.size()) {
+        const Piece &p = pieces[i];
+        const int g = ceil_log2(lanes_of(p));
+        const int size = 1 << g;
+        if (lane + size > 64) break;
+        gmax = std::max(gmax, g);
+        any_accum = any_accum || p.accum;
+        if (stream) {
+          int slot = 0;  // position among the piece's slots: the carry first, then the arcs
+          const int n_slots = (p.end - p.begin) + (p.accum ? 1 : 0);
+          for (int r = 0; r < size; ++r) {
+            uint32_t c = ((uint32_t)p.state << 3) | ((uint32_t)g << 20);
+            if (r == 0) c |= (1u << 31) | (p.accum ? (1u << 30) : 0u);
+            ctl[lane + r] = c;
+            for (int j = 0; j < U; ++j, ++slot) {
+              if (slot >= n_slots) continue;
+              const size_t at = (size_t)(lane + r) * U + j;
+              if (p.accum && slot == 0) {
+                rec[at] = ((uint32_t)p.state << 3) | (unit_label << 16);
+              } else {
+                const int32_t arc = list[p.begin + slot - (p.accum ? 1 : 0)];
+                rec[at] = ((uint32_t)other(arc) << 3) | ((uint32_t)label[arc] << 16);
+                pm[at] = arc;
+              }
+            }
           }
         }
+        lane += size;
+        ++i;
       }
-      lane += size;
-      ++i;
+      if (stream) {
+        for (int l = 0; l < 64; ++l) ctl[l] |= ((uint32_t)gmax << 23) | (any_accum ? (1u << 26) : 0u);
+        stream->insert(stream->end(), ctl, ctl + 64);
+        stream->insert(stream->end(), rec.begin(), rec.end());
+        perm->insert(perm->end(), pm.begin(), pm.end());
+      }
+      ++count.tiles;
+      if (gmax > 3) ++count.wide;
     }
-    for (int l = 0; l < 64; ++l) ctl[l] |= ((uint32_t)gmax << 20) | (any_accum ? (1u << 23) : 0u);
-    if (stream) {
-      stream->insert(stream->end(), ctl, ctl + 64);
-      stream->insert(stream->end(), rec.begin(), rec.end());
-      perm->insert(perm->end(), pm.begin(), pm.end());
-    }
-    ++n_tiles;
   }
 }
 
@@ -175,29 +201,38 @@ void schedule(Lat &L, int vocab, const Opts &o) {
   auto dst_of = [&](int a) { return L.dst[a]; };
   auto src_of = [&](int a) { return L.src[a]; };
   const uint32_t null_label = (uint32_t)vocab;
-  // slots per lane: fewest tiles wins (tiles are the unit of time); among U whose tile
-  // count is within 10 % of the best the smallest wins (bytes, gathers per tile)
-  auto pick_u = [&](bool backward) {
-    if (o.slots_per_lane == 1 || o.slots_per_lane == 2 || o.slots_per_lane == 4) return o.slots_per_lane;
-    int cnt[3] = {0, 0, 0};
+  // Slots per lane U and the largest group (narrow / wide) per direction: the cheapest
+  // program by a cost model of the sweep kernel -- cycles per tile as measured on MI355X
+  // (one wave): ~330 + 55 U, and ~450 more for a tile on the general
+  // path; a program without wide tiles also saves the per-tile test for them.
+  auto pick = [&](bool backward, int &u_out, int &wide_out) {
     const int us[3] = {1, 2, 4};
-    for (int q = 0; q < 3; ++q)
-      for (int t = 1; t <= D; ++t) {
-        if (backward) emit_level(by_height[t], us[q], null_label, out_of, dst_of, out_list, L.label, nullptr, nullptr, cnt[q]);
-        else emit_level(by_depth[t], us[q], null_label, in_of, src_of, in_list, L.label, nullptr, nullptr, cnt[q]);
+    double best = 0.0;
+    bool have = false;
+    for (int q = 0; q < 3; ++q) {
+      if ((o.slots_per_lane == 1 || o.slots_per_lane == 2 || o.slots_per_lane == 4) && us[q] != o.slots_per_lane) continue;
+      for (int wide = 0; wide < 2; ++wide) {
+        TileCount c;
+        for (int t = 1; t <= D; ++t) {
+          if (backward) emit_level(by_height[t], us[q], wide ? 6 : 3, null_label, out_of, dst_of, out_list, L.label, nullptr, nullptr, c);
+          else emit_level(by_depth[t], us[q], wide ? 6 : 3, null_label, in_of, src_of, in_list, L.label, nullptr, nullptr, c);
+        }
+        if (wide && c.wide == 0) continue;  // same program as the narrow one
+        const double cost = (double)c.tiles * (330.0 + 55.0 * us[q] + (wide ? 60.0 : 0.0)) + 450.0 * c.wide;
+        if (!have || cost < best) { have = true; best = cost; u_out = us[q]; wide_out = wide; }
       }
-    const int best = std::min(cnt[0], std::min(cnt[1], cnt[2]));
-    for (int q = 0; q < 3; ++q)
-      if (cnt[q] * 10 <= best * 11) return us[q];
-    return 4;
+    }
   };
-  L.bwd_u = pick_u(true);
-  L.fwd_u = pick_u(false);
+  pick(true, L.bwd_u, L.bwd_wide);
+  pick(false, L.fwd_u, L.fwd_wide);
   L.fwd.clear(); L.bwd.clear(); L.fwd_perm.clear(); L.bwd_perm.clear();
+  TileCount cb, cf;
   for (int t = 1; t <= D; ++t) {
-    emit_level(by_height[t], L.bwd_u, null_label, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, L.bwd_tiles);
-    emit_level(by_depth[t], L.fwd_u, null_label, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, L.fwd_tiles);
+    emit_level(by_height[t], L.bwd_u, L.bwd_wide ? 6 : 3, null_label, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, cb);
+    emit_level(by_depth[t], L.fwd_u, L.fwd_wide ? 6 : 3, null_label, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, cf);
   }
+  L.bwd_tiles = cb.tiles;
+  L.fwd_tiles = cf.tiles;
 }
 
 template <class F>
@@ -251,7 +286,7 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
     m[NFST_META_FWD_OFF] = (int32_t)fw; m[NFST_META_FWD_TILES] = L.fwd_tiles;
     m[NFST_META_BWD_OFF] = (int32_t)bw; m[NFST_META_BWD_TILES] = L.bwd_tiles;
     m[NFST_META_SINK] = L.sink; m[NFST_META_N_REACH] = L.n_reach; m[NFST_META_DEPTH] = L.depth;
-    m[NFST_META_N_DP] = L.n_dp; m[NFST_META_FWD_U] = L.fwd_u; m[NFST_META_BWD_U] = L.bwd_u;
+    m[NFST_META_N_DP] = L.n_dp; m[NFST_META_FWD_U] = L.fwd_u | (L.fwd_wide << 8); m[NFST_META_BWD_U] = L.bwd_u | (L.bwd_wide << 8);
     m[NFST_META_FWD_SLOT_OFF] = (int32_t)fs; m[NFST_META_BWD_SLOT_OFF] = (int32_t)bs;
     rows += L.n_rows; arcs += (int64_t)L.src.size(); dp += L.n_dp;
     // tile sizes are multiples of 64 words, so every lattice's stream starts on a

@@ -48,11 +48,6 @@ __device__ __forceinline__ ME exp_split(float x) {
   return r;
 }
 
-__device__ __forceinline__ void me_acc(float &M, int &E, float mt, int et) {
-  if (et > E) { M = ldexpf(M, E - et); E = et; }
-  M += ldexpf(mt, et - E);
-}
-
 // normalise a sum to mantissa in [0.5, 1).  A zero sum keeps mantissa 0 (frexp(0) = 0,
 // exponent 0): its exponent stays near kEZero, which never wins a max against a real
 // term, so no select is needed.
@@ -74,7 +69,7 @@ __device__ __forceinline__ float me_log32(float2 v) {
 
 struct Meta {
   int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_tiles, bwd_off, bwd_tiles, sink, n_reach, depth, n_dp,
-      fwd_u, bwd_u, fwd_slot_off, bwd_slot_off;
+      fwd_u, bwd_u, fwd_wide, bwd_wide, fwd_slot_off, bwd_slot_off;
 };
 __device__ __forceinline__ Meta load_meta(const int32_t *meta, int b) {
   const int32_t *m = meta + (size_t)b * NFST_META_WORDS;
@@ -84,7 +79,10 @@ __device__ __forceinline__ Meta load_meta(const int32_t *meta, int b) {
   r.fwd_off = m[NFST_META_FWD_OFF]; r.fwd_tiles = m[NFST_META_FWD_TILES];
   r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_tiles = m[NFST_META_BWD_TILES];
   r.sink = m[NFST_META_SINK]; r.n_reach = m[NFST_META_N_REACH]; r.depth = m[NFST_META_DEPTH];
-  r.n_dp = m[NFST_META_N_DP]; r.fwd_u = m[NFST_META_FWD_U]; r.bwd_u = m[NFST_META_BWD_U];
+  r.n_dp = m[NFST_META_N_DP];
+  // slots per lane, and bit 8: the program has tiles with groups wider than 8 lanes
+  r.fwd_u = m[NFST_META_FWD_U] & 0xff; r.bwd_u = m[NFST_META_BWD_U] & 0xff;
+  r.fwd_wide = (m[NFST_META_FWD_U] >> 8) & 1; r.bwd_wide = (m[NFST_META_BWD_U] >> 8) & 1;
   r.fwd_slot_off = m[NFST_META_FWD_SLOT_OFF]; r.bwd_slot_off = m[NFST_META_BWD_SLOT_OFF];
   return r;
 }
@@ -111,27 +109,35 @@ struct Extra {
 // earlier tile wrote, so a sweep needs no barrier at all, and the alpha and beta
 // sweeps of a lattice run as two independent waves of the workgroup.
 //
-// control word: [0:13) state id | [13] leader lane (stores the state's sum)
-//               [14] accumulate (continuation of a state with more than 64*U arcs)
-//               [16:19) g: the state's lanes are the 2^g-aligned group of 2^g lanes
-//               [20:23) largest g in this tile (same in every lane)
-//               [23] the tile holds an accumulate piece (same in every lane)
-// record:       [0:16) operand state | [16:32) label (vocab = the null label: weight 0)
+// control word: [0:16) 8 x state id (the byte offset of its value in the alpha / beta array)
+//               [20:23) g: the state's lanes are the 2^g-aligned group of 2^g lanes
+//               [23:26) largest g in this tile (same in every lane)
+//               [26] the tile holds a continuation piece (same in every lane)
+//               [30] continuation piece (its first record is the carry)  [31] leader lane
+//               (stores the state's sum)
+// record:       [0:16) 8 x operand state | [16:32) label (vocab = the null label: weight 0,
+//               vocab + 1 = the unit label of a carry record: weight 1)
 //
-// The program does not depend on DP values, so a helper wave of the workgroup (the
-// "decoder") runs far ahead of the sweep: it loads tiles from HBM into registers
-// (kLoadAhead tiles in flight), turns every record into what the sweep needs -- the LDS
+// The program does not depend on DP values, so two helper waves of the workgroup run far
+// ahead of the sweep.  The LOADER copies tiles from HBM into a small staging ring in LDS
+// with global_load_lds (LDS-DMA, no VGPR staging; kDmaAhead tiles in flight, counted
+// s_waitcnt vmcnt) -- issuing an LDS-DMA costs the issuing wave 60-100 cycles, which is
+// why this is a wave of its own.  The DECODER turns every record into what the sweep
+// needs -- the LDS
 // address of the operand and the (mantissa, exponent) weight of the arc, label weight x
 // per-arc extra -- and writes the decoded tile into a ring of R slots in LDS.  The sweep
 // wave reads only decoded tiles: nothing but the dependency chain is left on it.
 //
 // decoded tile, 64 * (1 + 3U) words:
-//   [0, 64)            word 0 per lane: [0:20) LDS byte address of the state's value
-//                      [20:23) g  [23:26) tile gmax  [26] tile has accumulate pieces
-//                      [30] accumulate  [31] leader
+//   [0, 64)            word 0 per lane: the control word + the LDS address of alpha / beta:
+//                      [0:20) LDS byte address of the state's value, the rest as above
 //   [64, 64 + 64U)     U operand LDS byte addresses per lane
 //   then               (m, e) weights, slots (2k, 2k+1) of all lanes in block k (16 B per lane)
-constexpr int kLoadAhead = 6;                   // tiles the decoder keeps in flight
+// tiles the loader keeps in flight (HBM -> LDS by LDS-DMA) and raw-tile staging slots per
+// sweep: deep when a workgroup has a CU's LDS to itself, shallow when two share it
+constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = 6;
+constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
+constexpr int kRawWordsX = kRawWords + 64 * 4;  // + the slots' canonical arc ids (kernels with per-arc extras)
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
 constexpr int kMaxRing = 8, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
 
@@ -274,145 +280,242 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // LDS accesses of one wave execute in order and LDS is coherent within the CU, so
 // "write slot -> store land" / "load land -> read slot" need no barrier.
 
-// raw tiles in flight in the decoder's registers (sized for U = 4)
-struct RawTiles {
-  uint32_t ctl[kLoadAhead];
-  uint32_t rc[kLoadAhead][4];
-  int32_t pm[kLoadAhead][4];   // canonical arcs of the slots (only with per-arc extras)
-  float xa[kLoadAhead][4];     // their table weights / caller scores
-  float xb[kLoadAhead][4];
-};
+// LDS-DMA (global_load_lds_*): lane i's `bytes` go to LDS address m0 + i*bytes.  Issued
+// from inline asm on purpose: the compiler then keeps no record of a pending LDS-DMA and
+// does not put s_waitcnt vmcnt(0) in front of every LDS access; the counted waits are
+// placed by hand (vm_wait).  In-flight data never lives in registers, so no compiler-made
+// register copy can touch it early.  Only full-wave 4- and 16-byte forms are used (the
+// 12-byte and exec-masked forms do not lay lanes out at lane x size on gfx950).
+__device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void *gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {  // at most N vector-memory operations of this wave stay in flight
+  static_assert(N >= 0 && N <= 63, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-// every variant writes all four record / arc registers of the set: identical stores in the
-// branches of a run-time dispatch on U keep the register sets out of scratch memory
+// LDS-DMA instructions per tile
 template <int U, bool EXTRA>
-__device__ __forceinline__ void raw_load(const uint32_t *g, const int32_t *perm, int tile, int lane, RawTiles &w,
-                                         int d) {
-  const uint32_t *base = g + (size_t)tile * (64 * (1 + U));
-  const uint32_t c = base[lane];
-  const uint32_t *r = base + 64 + lane * U;
-  const int32_t *q = perm + (size_t)tile * (64 * U) + lane * U;
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  int4 a = make_int4(-1, -1, -1, -1);
+struct DmaOps { static constexpr int value = (U == 2 ? 3 : 2) + (EXTRA ? (U == 2 ? 2 : 1) : 0); };
+
+// raw staging slot: [64 control words][64 U records]([64 U canonical arc ids])
+template <int U, bool EXTRA>
+__device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *perm, int tile, uint32_t slot_addr, int lane) {
+  const uint32_t *src = g + (size_t)tile * (64 * (1 + U));
+  const int32_t *q = perm + (size_t)tile * (64 * U);
+  lds_dma4(src + lane, slot_addr);
   if (U == 4) {
-    v = *reinterpret_cast<const uint4 *>(r);
-    if (EXTRA) a = *reinterpret_cast<const int4 *>(q);
+    lds_dma16(src + 64 + lane * 4, slot_addr + 256);
+    if (EXTRA) lds_dma16(q + lane * 4, slot_addr + 256 + 1024);
   } else if (U == 2) {
-    const uint2 t = *reinterpret_cast<const uint2 *>(r);
-    v.x = t.x; v.y = t.y;
-    if (EXTRA) { const int2 u = *reinterpret_cast<const int2 *>(q); a.x = u.x; a.y = u.y; }
+    lds_dma4(src + 64 + lane, slot_addr + 256);
+    lds_dma4(src + 128 + lane, slot_addr + 512);
+    if (EXTRA) { lds_dma4(q + lane, slot_addr + 768); lds_dma4(q + 64 + lane, slot_addr + 1024); }
   } else {
-    v.x = r[0];
-    if (EXTRA) a.x = q[0];
-  }
-  w.ctl[d] = c;
-  w.rc[d][0] = v.x; w.rc[d][1] = v.y; w.rc[d][2] = v.z; w.rc[d][3] = v.w;
-  if (EXTRA) { w.pm[d][0] = a.x; w.pm[d][1] = a.y; w.pm[d][2] = a.z; w.pm[d][3] = a.w; }
-}
-
-// per-arc extras of the tile in register set d (its arc ids have arrived): issued two
-// tiles before they are needed
-template <int U>
-__device__ __forceinline__ void extras_load(const Extra ex, RawTiles &w, int d) {
-#pragma unroll
-  for (int j = 0; j < U; ++j) {
-    const int arc = w.pm[d][j];
-    w.xa[d][j] = (arc >= 0 && ex.arc_w) ? ex.arc_w[arc] : 0.0f;
-    w.xb[d][j] = (arc >= 0 && ex.arc_scores) ? ex.arc_scores[arc] : 0.0f;
+    lds_dma4(src + 64 + lane, slot_addr + 256);
+    if (EXTRA) lds_dma4(q + lane, slot_addr + 512);
   }
 }
 
-// decoder wave, part 1 (kernel entry, before anything else): the first loads need
-// nothing from LDS, so they are in flight while the workgroup initialises
+// ---- loader wave ------------------------------------------------------------------
+// flags (LDS words, all only grow): rland = raw tiles 0 .. rland-1 have landed in the
+// staging ring; the decoder's `land` (tiles decoded) tells which staging slots are free.
+// part 1 (kernel entry, before anything else): the first ring-full needs no hand-shake,
+// so it is in flight while the workgroup initialises
 template <bool EXTRA>
-__device__ __forceinline__ void decoder_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, int lane,
-                                              RawTiles &w) {
-#pragma unroll
-  for (int d = 0; d < kLoadAhead; ++d) {
-    if (d < n_tiles) {
-      if (U == 4) raw_load<4, EXTRA>(g, perm, d, lane, w, d);
-      else if (U == 2) raw_load<2, EXTRA>(g, perm, d, lane, w, d);
-      else raw_load<1, EXTRA>(g, perm, d, lane, w, d);
+__device__ __forceinline__ void loader_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
+                                             int RS, int lane) {
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw);
+  const int n = min(n_tiles, RS);
+  for (int d = 0; d < n; ++d) {
+    if (U == 4) tile_issue<4, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else if (U == 2) tile_issue<2, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else tile_issue<1, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+  }
+}
+
+// blocks until at most `tiles` tiles (OPS LDS-DMA instructions each) are in flight;
+// vmcnt takes an immediate, hence the chain
+template <int OPS, int MAXT>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if (MAXT > 0 && tiles >= MAXT) vm_wait<(OPS * MAXT > 63 ? 63 : OPS * MAXT)>();
+  else if (MAXT > 0) wait_tiles_in_flight<OPS, (MAXT > 0 ? MAXT - 1 : 0)>(tiles);
+  else vm_wait<0>();
+}
+
+// part 2: streams the rest of the tile program into the staging ring.  Copies complete
+// in order, so "at most k tiles in flight" means tiles 0 .. issued-k-1 have landed: after
+// an issue the loader waits with k = AHEAD; whenever it cannot issue (ring full, or the
+// whole program issued) it publishes the oldest unpublished tile with the exact count.
+// `land` is the decoder's progress: when it publishes tile t the raw words of tiles 0 .. t+1
+// are in its registers, so the staging slot of tile i is certainly free once land >= i + 1.
+template <int U, bool EXTRA, int AHEAD>
+__device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int RS,
+                                            const int *land, int *rland, int lane) {
+  constexpr int OPS = DmaOps<U, EXTRA>::value;
+  static_assert(OPS * AHEAD <= 63, "vmcnt is 6 bits");
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
+  int issued = min(n_tiles, RS);  // loader_start issued these
+  uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
+  int freed = 0;                  // copy of the decoder's counter
+  int pub = 0;
+  unsigned long long l_begin, l_end, lw0, lw1, lwait_a = 0, lwait_b = 0, lsleeps = 0, lissues = 0; TSTAMP(l_begin);
+  while (pub < n_tiles) {
+    if (issued < n_tiles && issued - freed < RS) {
+      tile_issue<U, EXTRA>(g, perm, issued, rb, lane);
+      ++issued;
+      rb = (rb + RB == raw_end) ? raw_base : rb + RB;
+      ++lissues;
+      if (issued - pub > AHEAD) {
+        TSTAMP(lw0);
+        vm_wait<OPS * AHEAD>();
+        TSTAMP(lw1); lwait_a += lw1 - lw0;
+        pub = issued - AHEAD;
+        lds_flag_store(rland, pub);
+      }
+      continue;
+    }
+    if (pub < issued) {  // nothing to issue right now: publish the oldest tile in flight
+      TSTAMP(lw0);
+      wait_tiles_in_flight<OPS, AHEAD>(issued - pub - 1);
+      TSTAMP(lw1); lwait_b += lw1 - lw0;
+      ++pub;
+      lds_flag_store(rland, pub);
+    }
+    if (issued < n_tiles) {
+      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (pub == issued && issued - freed >= RS) { ++lsleeps; __builtin_amdgcn_s_sleep(1); }
     }
   }
+  TSTAMP(l_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = l_end - l_begin; o[1] = lwait_a; o[2] = lwait_b; o[3] = n_tiles; o[4] = lsleeps; o[5] = lissues; }
 }
 
-// decoder wave, part 2: decodes the tile program g into the ring
+// ---- decoder wave -----------------------------------------------------------------
+// flags: land = tiles 0 .. land-1 are decoded and in the ring (written here),
+// prog = tiles 0 .. prog-1 are consumed by the sweep, their ring slots are free.
+// LDS accesses of one wave execute in order and LDS is coherent within the CU, so
+// "write slot -> store land" / "load land -> read slot" need no barrier.
+// raw words of one tile in the decoder's registers
 template <int U, bool EXTRA>
-__device__ __forceinline__ void tile_decoder(RawTiles &w, const uint32_t *g, const int32_t *perm, int n_tiles,
+struct RawRegs {
+  uint32_t ctl;
+  uint32_t rc[U];
+  int32_t pm[EXTRA ? U : 1];
+};
+template <int U, bool EXTRA>
+__device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<U, EXTRA> &w) {
+  w.ctl = *(const lds_u32 *)(uintptr_t)(rb + lane * 4);
+  if (U == 4) {
+    const v4u v = *(const lds_v4u *)(uintptr_t)(rb + 256 + lane * 16);
+    w.rc[0] = v.x; w.rc[1 % U] = v.y; w.rc[2 % U] = v.z; w.rc[3 % U] = v.w;
+    if (EXTRA) {
+      const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 256 + 1024 + lane * 16);
+      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
+    }
+  } else if (U == 2) {
+    const v2u v = *(const lds_v2u *)(uintptr_t)(rb + 256 + lane * 8);
+    w.rc[0] = v.x; w.rc[1 % U] = v.y;
+    if (EXTRA) {
+      const v2u a = *(const lds_v2u *)(uintptr_t)(rb + 768 + lane * 8);
+      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y;
+    }
+  } else {
+    w.rc[0] = *(const lds_u32 *)(uintptr_t)(rb + 256 + lane * 4);
+    if (EXTRA) w.pm[0] = (int)*(const lds_u32 *)(uintptr_t)(rb + 512 + lane * 4);
+  }
+}
+
+template <int U, bool EXTRA>
+__device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, int RS, const int *rland,
                                              uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
                                              const float2 *th_, const Extra ex, int lane) {
-  constexpr int D = kLoadAhead;
-  constexpr int SW = 64 * (1 + 3 * U);
-  const lds_v2f *th = (const lds_v2f *)th_;
+  if (n_tiles <= 0) return;
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
+  const uint32_t th_base = lds_addr(th_);
   const uint32_t val_base = lds_addr(val);
-  const uint32_t ring_base = lds_addr(ring);
-  int slot = 0, freed = 0;
-  unsigned long long d_begin, d_end, dw0, dw1, dwaited = 0, dpolls = 0; TSTAMP(d_begin);
-  if (EXTRA) {
-    if (n_tiles > 0) extras_load<U>(ex, w, 0);
-    if (n_tiles > 1) extras_load<U>(ex, w, 1);
-  }
-  for (int t0 = 0; t0 < n_tiles; t0 += D) {
+  const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+  const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
+  uint32_t sb = ring_base;  // decoded slot of tile t
+  uint32_t rb = raw_base;   // staging slot of the tile whose raw words are fetched next
+  int freed = 0, landed = 0;
+  unsigned long long d_begin, d_end, dw0, dw1, dwaited = 0, dpolls = 0, lwaited = 0; TSTAMP(d_begin);
+  auto wait_raw = [&](int need) {
+    if (landed < need) { TSTAMP(dw0);
+    while (__builtin_expect(landed < need, 0)) {
+      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(rland));
+      if (landed < need) __builtin_amdgcn_s_sleep(1);
+    }
+    TSTAMP(dw1); lwaited += dw1 - dw0; }
+    asm volatile("" ::: "memory");
+  };
+  RawRegs<U, EXTRA> cur, nxt;
+  wait_raw(1);
+  raw_fetch<U, EXTRA>(rb, lane, cur);
+  for (int t = 0; t < n_tiles; ++t) {
+    // --- label weights of tile t (LDS gathers), then the raw words of tile t+1 in their
+    // shadow; past the end this reads a stale staging slot whose contents are never used
+    v2f tw[U];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int t = t0 + d;
-      if (t >= n_tiles) break;
-      if (EXTRA && t + 2 < n_tiles) extras_load<U>(ex, w, (d + 2) % D);
-      // --- decode
-      const uint32_t ctl = w.ctl[d];
-      const uint32_t w0 = (val_base + ((ctl & 0x1fffu) << 3)) | ((ctl & 0x00070000u) << 4) |
-                          ((ctl & 0x00f00000u) << 3) | ((ctl & (1u << 13)) << 18) | ((ctl & (1u << 14)) << 16);
-      uint32_t oa[U];
-      v2f tw[U];
+    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + ((cur.rc[j] >> 16) << 3));
+    rb = (rb + RB == raw_end) ? raw_base : rb + RB;
+    wait_raw(min(t + 2, n_tiles));
+    raw_fetch<U, EXTRA>(rb, lane, nxt);
+    asm volatile("" ::: "memory");
+    // --- control word and operand addresses: the packer's byte offsets + the array's base
+    const uint32_t w0 = cur.ctl + val_base;
+    uint32_t oa[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) oa[j] = (cur.rc[j] & 0xffffu) + val_base;
+    // --- the ring slot must be free: tile t - R consumed
+    if (__builtin_expect(t - freed >= R, 0)) {
+      TSTAMP(dw0);
+      while (t - freed >= R) {
+        freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
+        ++dpolls;
+        if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
+      }
+      TSTAMP(dw1); dwaited += dw1 - dw0;
+    }
+    asm volatile("" ::: "memory");
+    *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
+    if (U == 4) *(lds_v4u *)(uintptr_t)(sb + 256 + lane * 16) = v4u{oa[0], oa[1 % U], oa[2 % U], oa[3 % U]};
+    else if (U == 2) *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
+    else *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
+    if (EXTRA) {
+      // per-arc extras: plain loads, waited for in place (lattices with per-arc extras
+      // decode at about one memory latency per tile)
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t rc = w.rc[d][j];
-        tw[j] = th[rc >> 16];
-        oa[j] = val_base + ((rc & 0xffffu) << 3);
-      }
-      if (EXTRA) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          if (w.pm[d][j] >= 0) {
-            const ME x = exp_split(w.xa[d][j] + w.xb[d][j]);
-            tw[j].x *= x.m;
-            tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
-          }
+        if (cur.pm[j] >= 0) {
+          const ME x = exp_split(ex.at(cur.pm[j]));
+          tw[j].x *= x.m;
+          tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
         }
       }
-      // --- the slot must be free: tile t - R consumed
-      if (__builtin_expect(t - freed >= R, 0)) {
-        TSTAMP(dw0);
-        while (t - freed >= R) {
-          freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
-          ++dpolls;
-          if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
-        }
-        TSTAMP(dw1); dwaited += dw1 - dw0;
-      }
-      asm volatile("" ::: "memory");
-      const uint32_t sb = ring_base + (uint32_t)slot * (SW * 4);
-      *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
-      if (U == 4) {
-        *(lds_v4u *)(uintptr_t)(sb + 256 + lane * 16) = v4u{oa[0], oa[1 % U], oa[2 % U], oa[3 % U]};
-        *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
-        *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{tw[2 % U].x, tw[2 % U].y, tw[3 % U].x, tw[3 % U].y};
-      } else if (U == 2) {
-        *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
-        *(lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
-      } else {
-        *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
-        *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = tw[0];
-      }
-      // --- refill this register set, publish
-      if (t + D < n_tiles) raw_load<U, EXTRA>(g, perm, t + D, lane, w, d);
-      asm volatile("" ::: "memory");
-      lds_flag_store(land, t + 1);
-      slot = (slot + 1 == R) ? 0 : slot + 1;
     }
+    if (U == 4) {
+      *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+      *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{tw[2 % U].x, tw[2 % U].y, tw[3 % U].x, tw[3 % U].y};
+    } else if (U == 2) {
+      *(lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+    } else {
+      *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = tw[0];
+    }
+    asm volatile("" ::: "memory");
+    // tile t is decoded; the loader reads the same word: the raw words of tiles 0 .. t are
+    // in registers (tile t+1's may still be on their way: the loader keeps one slot clear)
+    lds_flag_store(land, t + 1);
+    sb = (sb + SB == ring_end) ? ring_base : sb + SB;
+    cur = nxt;
   }
-  TSTAMP(d_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = d_end - d_begin; o[1] = dwaited; o[2] = dpolls; o[3] = n_tiles; }
+  TSTAMP(d_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = d_end - d_begin; o[1] = dwaited; o[2] = dpolls; o[3] = n_tiles; o[4] = lwaited; }
 }
 
 // decoded tile in the sweep wave's registers
@@ -424,9 +527,7 @@ struct TileDec {
 };
 
 template <int U>
-__device__ __forceinline__ void dec_fetch(uint32_t ring_base, int slot, int lane, TileDec<U> &d) {
-  constexpr int SW = 64 * (1 + 3 * U);
-  const uint32_t sb = ring_base + (uint32_t)slot * (SW * 4);
+__device__ __forceinline__ void dec_fetch(uint32_t sb, int lane, TileDec<U> &d) {
   d.w0 = *(const lds_u32 *)(uintptr_t)(sb + lane * 4);
   if (U == 4) {
     const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 256 + lane * 16);
@@ -447,13 +548,17 @@ __device__ __forceinline__ void dec_fetch(uint32_t ring_base, int slot, int lane
 
 // One sum-product sweep, run by ONE wave over the decoded ring.  The sweep is one
 // dependency chain (gather operands -> sum -> reduce over the state's lanes -> store ->
-// next tile's gathers); an iteration starts with the operand gathers of its tile and
-// fetches the next decoded tile in their shadow.
-template <int U>
+// next tile's gathers) and a single wave issues one instruction every ~4 cycles, a taken
+// branch costs ~20 and a scalar use of a fresh vector result ~25: an iteration is
+// straight-line code.  It starts with the operand gathers of its tile, fetches the next
+// decoded tile and prepares the stage masks in their shadow, and ends by moving the next
+// tile's wave-uniform flags to a scalar register.
+template <int U, bool WIDE>
 __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land,
                                            int lane) {
   if (n_tiles <= 0) return;
-  const uint32_t ring_base = lds_addr(ring);
+  constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;  // bytes per ring slot
+  const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
   unsigned long long t_begin, t_end, tw0, tw1, waited = 0, polls = 0; TSTAMP(t_begin);
   int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
   auto wait_landed = [&](int need) {
@@ -468,78 +573,57 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
     }
     asm volatile("" ::: "memory");
   };
-  const int last = n_tiles - 1;
-  int t1 = 0, slot1 = 0;  // tile fetched next: min(T + 1, last), and its ring slot
-  // iteration T: `cur` = tile T, `nxt` receives tile T+1
-  auto step = [&](int T, const TileDec<U> &cur, TileDec<U> &nxt, bool publish) {
+  uint32_t sb = ring_base;  // slot of the tile that is fetched next
+  // iteration T: `cur` = tile T with its uniform flags in `cu`; `nxt` receives tile T+1
+  auto step = [&](int T, const TileDec<U> &cur, uint32_t cu, TileDec<U> &nxt, uint32_t &cu_nxt, bool publish) {
     // --- operand gathers: the head of the dependency chain
     v2f vv[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)cur.opa[j];
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the gathers
-    // --- the next decoded tile (the last iteration re-reads the last tile's slot)
-    if (t1 < last) { ++t1; slot1 = (slot1 + 1 == R) ? 0 : slot1 + 1; }
-    wait_landed(t1 + 1);
-    dec_fetch<U>(ring_base, slot1, lane, nxt);
+    // --- the next decoded tile.  Past the end of the program this reads a stale slot
+    // whose contents are never used.
+    sb = (sb + SB == ring_end) ? ring_base : sb + SB;
+    wait_landed(min(T + 2, n_tiles));
+    dec_fetch<U>(sb, lane, nxt);
     asm volatile("" ::: "memory");
-    // --- everything that only needs the tile's control word is computed in the shadow of
-    // the gathers: which reduce variant (wave-uniform: the tile's largest group has up to
-    // 4 lanes, 8 lanes, or is wider / the tile holds continuation pieces of states with
-    // more than 64 U arcs), the per-lane stage masks, the store address
+    // --- what only needs the tile's control word: stage masks (lanes whose state owns
+    // more than 2^s lanes), leader lanes, store address
     const uint32_t w0 = cur.w0;
     const int gl = (int)((w0 >> 20) & 7u);
-    const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane(w0);
     lds_v2f *dst = (lds_v2f *)(uintptr_t)(w0 & 0xfffffu);
     const bool leader = (int)w0 < 0;
     const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
                    m2 = __builtin_amdgcn_ballot_w64(gl > 2);
-    const bool general = (cu & (3u << 25)) != 0;
-    const bool three = (cu & (3u << 23)) == (3u << 23);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // --- this lane's partial sum with one shared exponent
-    auto local_sum = [&](float &M, int &E) {
-      float mt[U];
-      int et[U];
+    float mt[U];
+    int et[U];
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        mt[j] = cur.tw[j].x * vv[j].x;
-        et[j] = __float_as_int(cur.tw[j].y) + __float_as_int(vv[j].y);
-      }
-      E = et[0];
+    for (int j = 0; j < U; ++j) {
+      mt[j] = cur.tw[j].x * vv[j].x;
+      et[j] = __float_as_int(cur.tw[j].y) + __float_as_int(vv[j].y);
+    }
+    int E = et[0];
 #pragma unroll
-      for (int j = 1; j < U; ++j) E = max(E, et[j]);
-      M = ldexpf(mt[0], et[0] - E);
+    for (int j = 1; j < U; ++j) E = max(E, et[j]);
+    float M = ldexpf(mt[0], et[0] - E);
 #pragma unroll
-      for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
-    };
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
     // --- reduce over the state's lanes (max of exponents, one rescale, sum), normalise,
-    // store.  The branch is taken before the gathers are back; the two
-    // common variants run their stages under execution masks (seg_reduce_exec).
-    float M;
-    int E;
-    if (__builtin_expect(general, 0)) {
-      local_sum(M, E);
+    // store.  Groups of up to 8 lanes run three stages under execution masks (a stage
+    // nobody takes part in is an empty mask).  Only programs the packer marked WIDE have
+    // tiles with larger groups (flagged wave-uniformly); those take the general path.
+    if (WIDE && __builtin_expect((cu & (1u << 25)) != 0, 0)) {
       seg_reduce_n<6>(M, E, gl);
-      if (leader) {
-        if (w0 & (1u << 30)) {
-          const v2f old = *dst;
-          me_acc(M, E, old.x, __float_as_int(old.y));
-        }
-        const float2 r = me_pack(M, E);
-        *dst = v2f{r.x, r.y};
-      }
-    } else if (three) {
-      local_sum(M, E);
-      seg_reduce_exec<3>(M, E, m0, m1, m2);
       if (leader) {
         const float2 r = me_pack(M, E);
         *dst = v2f{r.x, r.y};
       }
     } else {
-      local_sum(M, E);
-      seg_reduce_exec<2>(M, E, m0, m1, m2);
+      seg_reduce_exec<3>(M, E, m0, m1, m2);
       if (leader) {
         const float2 r = me_pack(M, E);
         *dst = v2f{r.x, r.y};
@@ -547,34 +631,49 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
     }
     // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
     if (publish) lds_flag_store(prog, T + 2);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (WIDE) cu_nxt = (uint32_t)__builtin_amdgcn_readfirstlane(nxt.w0);
   };
   wait_landed(1);
   TileDec<U> da, db;
-  dec_fetch<U>(ring_base, 0, lane, da);
+  dec_fetch<U>(sb, lane, da);
   asm volatile("" ::: "memory");
+  uint32_t ca = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane(da.w0) : 0u, cb = 0;
   // two iterations per trip so that the register roles alternate without copies
   for (int T = 0; T < n_tiles; T += 2) {
-    step(T, da, db, false);
+    step(T, da, ca, db, cb, false);
     if (T + 1 >= n_tiles) break;
-    step(T + 1, db, da, true);
+    step(T + 1, db, cb, da, ca, true);
   }
   TSTAMP(t_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = t_end - t_begin; o[1] = waited; o[2] = polls; o[3] = n_tiles; }
 }
 
-// role dispatch: one wave sweeps, another decodes for it
-template <bool EXTRA>
-__device__ __forceinline__ void run_sweep(bool is_consumer, int U, RawTiles &w, const uint32_t *g,
+// role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder.
+// flags: [0] prog [1] land [2] rland
+template <bool EXTRA, int AHEAD>
+__device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *raw, int RS, const uint32_t *g,
                                           const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
                                           float2 *val, const float2 *th, const Extra ex, int lane) {
-  int *prog = flags, *land = flags + 1;
-  if (is_consumer) {
-    if (U == 4) tile_sweep<4>(n_tiles, ring, R, prog, land, lane);
-    else if (U == 2) tile_sweep<2>(n_tiles, ring, R, prog, land, lane);
-    else tile_sweep<1>(n_tiles, ring, R, prog, land, lane);
+  int *prog = flags, *land = flags + 1, *rland = flags + 2;
+  if (role == 0) {
+    if (wide) {
+      if (U == 4) tile_sweep<4, true>(n_tiles, ring, R, prog, land, lane);
+      else if (U == 2) tile_sweep<2, true>(n_tiles, ring, R, prog, land, lane);
+      else tile_sweep<1, true>(n_tiles, ring, R, prog, land, lane);
+    } else {
+      if (U == 4) tile_sweep<4, false>(n_tiles, ring, R, prog, land, lane);
+      else if (U == 2) tile_sweep<2, false>(n_tiles, ring, R, prog, land, lane);
+      else tile_sweep<1, false>(n_tiles, ring, R, prog, land, lane);
+    }
+  } else if (role == 1) {
+    if (U == 4) tile_decoder<4, EXTRA>(n_tiles, raw, RS, rland, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 2) tile_decoder<2, EXTRA>(n_tiles, raw, RS, rland, ring, R, prog, land, val, th, ex, lane);
+    else tile_decoder<1, EXTRA>(n_tiles, raw, RS, rland, ring, R, prog, land, val, th, ex, lane);
   } else {
-    if (U == 4) tile_decoder<4, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
-    else if (U == 2) tile_decoder<2, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
-    else tile_decoder<1, EXTRA>(w, g, perm, n_tiles, ring, R, prog, land, val, th, ex, lane);
+    if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else if (U == 2) tile_loader<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else tile_loader<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
   }
 }
 
@@ -585,21 +684,28 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
     ME x = exp_split(t[l]);
     th[l] = make_float2(x.m, __int_as_float(x.e));
   }
-  if (tid == 0) th[V] = make_float2(0.0f, __int_as_float(kEZero));  // the null label of empty slots
+  if (tid == 0) {
+    th[V] = make_float2(0.0f, __int_as_float(kEZero));  // the null label of empty slots
+    th[V + 1] = make_float2(0.5f, __int_as_float(1));       // weight one: the carry record of a continuation piece
+  }
 }
 
 // ------------------------------------------------------------------ LDS layout
-// [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V + null label)]
-// [label histogram: v4 float][ring 0: R decoded tiles][ring 1: R decoded tiles][4 flag words]  (16-B aligned)
+// [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V labels + null + unit)]
+// [label histogram: v4 float][per sweep: R decoded tiles, kRawSlots raw tiles][4 flag words per sweep]  (16-B aligned)
 struct LdsPlan {
   int rows2, v2, v4;
   __host__ __device__ LdsPlan(int max_rows, int vocab)
-      : rows2((max_rows + 1) & ~1), v2((vocab + 2) & ~1), v4((vocab + 3) & ~3) {}
-  __host__ __device__ int64_t fb_bytes(int R) const {
-    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * (int64_t)R * kSlotWords * 4 + 16;
+      : rows2((max_rows + 1) & ~1), v2((vocab + 3) & ~1), v4((vocab + 3) & ~3) {}
+  // words of one sweep's rings
+  static __host__ __device__ int64_t sweep_words(int R, int RS, bool extra) {
+    return (int64_t)R * kSlotWords + (int64_t)RS * (extra ? kRawWordsX : kRawWords);
   }
-  __host__ __device__ int64_t bwd_bytes(int R) const {
-    return ((int64_t)rows2 + v2) * 8 + (int64_t)R * kSlotWords * 4 + 16;
+  __host__ __device__ int64_t fb_bytes(int R, int RS, bool extra) const {
+    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * sweep_words(R, RS, extra) * 4 + 32;
+  }
+  __host__ __device__ int64_t bwd_bytes(int R, int RS, bool extra) const {
+    return ((int64_t)rows2 + v2) * 8 + sweep_words(R, RS, extra) * 4 + 16;
   }
 };
 
@@ -609,10 +715,10 @@ struct LdsPlan {
 // co-resident workgroups hide each other's latencies and 4 waves are cheaper.
 
 // ------------------------------------------------------------------ backward only
-// Wave 0 sweeps the by-source program from the sink; the other waves help with the
-// initialisation and the outputs.
+// Wave 0 sweeps the by-source program from the sink, wave 1 decodes for it, wave 2 loads
+// for the decoder; every wave helps with the initialisation and the outputs.
 template <int NT, bool EXTRA>
-__global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, float *logbeta,
+__global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, int RS, float *logbeta,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -623,20 +729,20 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   uint32_t *ring = (uint32_t *)(th + plan.v2);
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  RawTiles raw;
-  if (wv == 1)
-    decoder_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, lane, raw);
+  uint32_t *raw = ring + (size_t)R * kSlotWords;
+  if (wv == 2)
+    loader_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, raw, RS, lane);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
-  int *flags = (int *)(ring + (size_t)R * kSlotWords);
+  int *flags = (int *)(ring + LdsPlan::sweep_words(R, RS, EXTRA));
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
-    flags[0] = 0; flags[1] = 0;
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
   }
   __syncthreads();
-  if (wv < 2)  // wave 0 sweeps, wave 1 decodes the tile program into its ring
-    run_sweep<EXTRA>(wv == 0, m.bwd_u, raw, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
+  if (wv < 3)
+    run_sweep<EXTRA, (NT == 512 ? kDmaAheadDeep : kDmaAheadShared)>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
               m.bwd_tiles, ring, R, flags, beta, th, ex, lane);
   __syncthreads();
   if (tid == 0) {
@@ -670,7 +776,7 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // follows every wave of the block streams canonical arcs for the posteriors.
 template <int NT, bool EXTRA>
 __global__ __launch_bounds__(NT) void k_forward_backward(
-    nfst_batch lat, nfst_scores sc, int R, float *__restrict__ logalpha, float *__restrict__ logbeta,
+    nfst_batch lat, nfst_scores sc, int R, int RS, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
@@ -685,13 +791,16 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   constexpr bool has_extra = EXTRA;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool bwd_side = (wv == 0 || wv == 2);  // waves 0 / 2: beta sweep and its decoder; 1 / 3: alpha
+  // waves 0 / 2 / 4: beta sweep, its decoder and its loader; waves 1 / 3 / 5: the same for alpha
+  const bool bwd_side = (wv & 1) == 0;
   const uint32_t *my_prog = bwd_side ? lat.bwd_stream + m.bwd_off : lat.fwd_stream + m.fwd_off;
   const int32_t *my_perm = bwd_side ? lat.bwd_perm + m.bwd_slot_off : lat.fwd_perm + m.fwd_slot_off;
   const int my_tiles = bwd_side ? m.bwd_tiles : m.fwd_tiles;
   const int my_u = bwd_side ? m.bwd_u : m.fwd_u;
-  RawTiles raw;
-  if (wv == 2 || wv == 3) decoder_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, lane, raw);
+  const bool my_wide = (bwd_side ? m.bwd_wide : m.fwd_wide) != 0;
+  uint32_t *my_ring = bwd_side ? ring : ring + LdsPlan::sweep_words(R, RS, EXTRA);
+  uint32_t *my_raw = my_ring + (size_t)R * kSlotWords;
+  if (wv == 4 || wv == 5) loader_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, my_raw, RS, lane);
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -699,11 +808,11 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   __syncthreads();
-  int *flags = (int *)(ring + 2 * (size_t)R * kSlotWords);
+  int *flags = (int *)(ring + 2 * LdsPlan::sweep_words(R, RS, EXTRA));
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     alpha[0] = make_float2(0.5f, __int_as_float(1));
-    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
+    for (int i = 0; i < 8; ++i) flags[i] = 0;
   }
   __syncthreads();
   const bool want_post = posterior != nullptr || grad_theta != nullptr;
@@ -716,9 +825,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // posterior pass starts on data that is already there.
   constexpr int kSweepThreads = 256;
   constexpr int kHelpers = NT - kSweepThreads;
-  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice (fewer with per-arc extras: the decoder
-  // waves need the registers)
-  constexpr int kPre = (kHelpers > 0) ? (EXTRA ? 2 : 7) : 0;
+  constexpr int kPre = (kHelpers > 0) ? 7 : 0;  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice
   // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
   uint4 psd[kPre > 0 ? kPre : 1];
   uint2 plb[kPre > 0 ? kPre : 1];
@@ -732,10 +839,10 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       }
     }
   }
-  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode their tile programs
-  if (wv < 4)
-    run_sweep<EXTRA>(wv < 2, my_u, raw, my_prog, my_perm, my_tiles, bwd_side ? ring : ring + (size_t)R * kSlotWords,
-              R, bwd_side ? flags : flags + 2, bwd_side ? beta : alpha, th, ex, lane);
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 4 / 5 load for them
+  if (wv < 6)
+    run_sweep<EXTRA, (NT == 1024 ? kDmaAheadDeep : kDmaAheadShared)>(wv >> 1, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
+                     bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex, lane);
   __syncthreads();
   const float2 zme = beta[0];
   if (tid == 0) {
@@ -850,9 +957,9 @@ __global__ __launch_bounds__(64) void k_viterbi(nfst_batch lat, nfst_scores sc, 
       float s0 = tg[rc >> 16];
       if (arc_w) s0 += arc_w[ca];
       if (sc.arc_scores) s0 += sc.arc_scores[ca];
-      vit_take(bv, ba, s0 + v[rc & 0xffffu], ca);
+      vit_take(bv, ba, s0 + v[(rc & 0xffffu) >> 3], ca);
     }
-    const int gl = (int)((ctl >> 16) & 7u);
+    const int gl = (int)((ctl >> 20) & 7u);
     for (int st = 0; st < 6; ++st) {
       int partner;
       if (st == 0) partner = lane ^ 1;
@@ -864,9 +971,9 @@ __global__ __launch_bounds__(64) void k_viterbi(nfst_batch lat, nfst_scores sc, 
       const int oa = __shfl(ba, partner);
       if (gl > st) vit_take(bv, ba, ov, oa);
     }
-    if (ctl & (1u << 13)) {
-      const uint32_t sid = ctl & 0x1fffu;
-      if ((ctl & (1u << 14)) && bp[sid] >= 0) vit_take(bv, ba, v[sid], bp[sid]);
+    if (ctl & (1u << 31)) {
+      const uint32_t sid = (ctl & 0xffffu) >> 3;
+      if ((ctl & (1u << 30)) && bp[sid] >= 0) vit_take(bv, ba, v[sid], bp[sid]);
       v[sid] = bv;
       bp[sid] = (ba == kNone) ? -1 : ba;
     }
@@ -1346,20 +1453,7 @@ int nfst_device_available(void) {
 
 int64_t nfst_lds_bytes(const nfst_batch *lat) {
   if (!lat) return NFST_ERR_ARG;
-  return LdsPlan(lat->max_rows, lat->vocab).fb_bytes(kMinRing);
-}
-
-// ring slots per sweep: as many as the LDS budget of one workgroup allows (kMinRing .. kMaxRing);
-// with more lattices than CUs two workgroups share a CU's 160 KiB if the lattices are small enough
-static int ring_slots(int64_t fixed_bytes, int n_rings, bool share_cu) {
-  const int64_t slot = (int64_t)kSlotWords * 4 * n_rings;
-  if (share_cu) {
-    const int64_t r = (kMaxLds / 2 - fixed_bytes) / slot;
-    if (r >= kMinRing + 1) return (int)(r > kMaxRing ? kMaxRing : r);
-  }
-  const int64_t r = (kMaxLds - fixed_bytes) / slot;
-  if (r < kMinRing) return 0;
-  return (int)(r > kMaxRing ? kMaxRing : r);
+  return LdsPlan(lat->max_rows, lat->vocab).fb_bytes(kMinRing, kRawSlotsShared, lat->weighted != 0);
 }
 
 // number of CUs of the current device (cached per process; 256 on MI355X)
@@ -1376,23 +1470,51 @@ static int cu_count() {
   return n;
 }
 
+// Ring sizes per sweep from the LDS budget of one workgroup.  deep = the workgroup has a
+// CU's 160 KiB to itself (deep staging ring); otherwise two workgroups share it when the
+// lattices are small enough.  Returns R (decoded slots, kMinRing .. kMaxRing; 0 = does not
+// fit) and the staging slots in *rs.
+static int ring_slots(const LdsPlan &plan, bool fb, bool extra, bool deep, int *rs) {
+  const int n_rings = fb ? 2 : 1;
+  const int64_t slot = (int64_t)kSlotWords * 4 * n_rings;
+  auto fixed = [&](int RS) { return fb ? plan.fb_bytes(0, RS, extra) : plan.bwd_bytes(0, RS, extra); };
+  if (deep) {
+    *rs = kRawSlotsDeep;
+    const int64_t r = (kMaxLds - fixed(*rs)) / slot;
+    if (r >= kMinRing) return (int)(r > kMaxRing ? kMaxRing : r);
+    // a very large lattice: shallow staging ring, whatever is left for the decoded ring
+  } else {
+    *rs = kRawSlotsShared;
+    const int64_t r = (kMaxLds / 2 - fixed(*rs)) / slot;
+    if (r >= kMinRing + 1) return (int)(r > kMaxRing ? kMaxRing : r);
+  }
+  // (deep kernels run with a ring of kRawSlotsShared slots too: the loader then simply waits for
+  // the decoder earlier)
+  *rs = deep ? kDmaAheadDeep + 2 : kRawSlotsShared;
+  const int64_t r = (kMaxLds - fixed(*rs)) / slot;
+  if (r < kMinRing) return 0;
+  return (int)(r > kMaxRing ? kMaxRing : r);
+}
+
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta, double *logz64,
                   float *logz32, float *beta_me, void *stream) {
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
-  const int R = ring_slots(plan.bwd_bytes(0), 1, lat->n_lattices > cu_count());
+  const bool deep = lat->n_lattices <= cu_count();
+  int RS = 0;
+  const int R = ring_slots(plan, false, extra, deep, &RS);
   if (R == 0) return NFST_ERR_LIMIT;
-  const int64_t lds = plan.bwd_bytes(R);
+  const int64_t lds = plan.bwd_bytes(R, RS, extra);
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
   {                                                                                                    \
     if ((rc = set_lds(k_backward<NT, EX>, lds))) return rc;                                            \
     hipLaunchKernelGGL((k_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,             \
-                       (hipStream_t)stream, *lat, *scores, R, logbeta, logz64, logz32, (float2 *)beta_me); \
+                       (hipStream_t)stream, *lat, *scores, R, RS, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
-  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
-  if (lat->n_lattices <= cu_count()) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
+  if (deep) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
   else { if (extra) NFST_LAUNCH_BWD(256, true) else NFST_LAUNCH_BWD(256, false) }
 #undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
@@ -1406,24 +1528,24 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if ((rc = check_scores(lat, scores))) return rc;
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
-  const int R = ring_slots(plan.fb_bytes(0), 2, lat->n_lattices > cu_count());
+  const int cus = cu_count();
+  const bool deep = lat->n_lattices <= cus;
+  int RS = 0;
+  const int R = ring_slots(plan, true, extra, deep, &RS);
   if (R == 0) return NFST_ERR_LIMIT;
-  const int64_t lds = plan.fb_bytes(R);
+  const int64_t lds = plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
     if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
     hipLaunchKernelGGL((k_forward_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,      \
-                       (hipStream_t)stream, *lat, *scores, R, logalpha, logbeta, logz64, logz32, posterior, \
+                       (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, posterior, \
                        grad_theta, (float2 *)beta_me);                                                  \
   }
-  const int cus = cu_count();
-  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
-  // (the variants with per-arc extras need ~170 registers: 8 waves per workgroup at most)
-  if (extra) { if (lat->n_lattices <= cus) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(256, true) }
-  else if (lat->n_lattices <= cus) NFST_LAUNCH_FB(1024, false)
-  else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512, false)
-  else NFST_LAUNCH_FB(256, false)
+  if (deep) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
+  else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
+  else { if (extra) NFST_LAUNCH_FB(384, true) else NFST_LAUNCH_FB(384, false) }
 #undef NFST_LAUNCH_FB
   return hip_status(hipGetLastError());
 }

@@ -14,13 +14,14 @@ def replay(lat, b, direction, theta, extra=None):
     if direction == "fwd":
         s = lat.fwd_stream.cpu().numpy().view(np.uint32)
         perm = lat.fwd_perm.cpu().numpy()
-        off, tiles, U, slot0, start = (int(m[_lib.META_FWD_OFF]), int(m[_lib.META_FWD_TILES]), int(m[_lib.META_FWD_U]),
+        off, tiles, U, slot0, start = (int(m[_lib.META_FWD_OFF]), int(m[_lib.META_FWD_TILES]), int(m[_lib.META_FWD_U]) & 0xFF,
                                        int(m[_lib.META_FWD_SLOT_OFF]), 0)
     else:
         s = lat.bwd_stream.cpu().numpy().view(np.uint32)
         perm = lat.bwd_perm.cpu().numpy()
-        off, tiles, U, slot0, start = (int(m[_lib.META_BWD_OFF]), int(m[_lib.META_BWD_TILES]), int(m[_lib.META_BWD_U]),
+        off, tiles, U, slot0, start = (int(m[_lib.META_BWD_OFF]), int(m[_lib.META_BWD_TILES]), int(m[_lib.META_BWD_U]) & 0xFF,
                                        int(m[_lib.META_BWD_SLOT_OFF]), int(m[_lib.META_SINK]))
+    wide = (int(m[_lib.META_FWD_U if direction == "fwd" else _lib.META_BWD_U]) >> 8) & 1
     assert U in (1, 2, 4) and off % 64 == 0
     ST = 64 * (1 + U)
     src = lat.arc_src.cpu().numpy(); dst = lat.arc_dst.cpu().numpy(); lab = lat.arc_label.cpu().numpy()
@@ -34,27 +35,36 @@ def replay(lat, b, direction, theta, extra=None):
         ctl = s[base: base + 64]
         rec = s[base + 64: base + ST].reshape(64, U)
         pm = perm[slot0 + T * 64 * U: slot0 + (T + 1) * 64 * U].reshape(64, U)
-        gmax = int(ctl[0] >> 20) & 7
-        assert np.all(((ctl >> 20) & 7) == gmax)
+        gmax = int(ctl[0] >> 23) & 7
+        assert np.all(((ctl >> 23) & 7) == gmax)
         writes = {}
         lane = 0
         while lane < 64:
             c = int(ctl[lane])
-            g = (c >> 16) & 7
+            g = (c >> 20) & 7
             size = 1 << g
-            assert g <= gmax and lane % size == 0 and g <= 6
-            leader = (c >> 13) & 1
-            sid = c & 0x1FFF
+            assert g <= gmax and lane % size == 0 and g <= (6 if wide else 3)
+            leader = (c >> 31) & 1
+            assert (c & 7) == 0 and ((c >> 16) & 15) == 0
+            sid = (c & 0xFFFF) >> 3
             terms = []
+            carries = 0
             for r in range(size):
                 cr = int(ctl[lane + r])
-                assert ((cr >> 16) & 7) == g and (cr & 0x1FFF) == sid
-                assert ((cr >> 13) & 1) == (leader if r == 0 else 0)
+                assert ((cr >> 20) & 7) == g and ((cr & 0xFFFF) >> 3) == sid
+                assert ((cr >> 31) & 1) == (leader if r == 0 else 0)
                 for j in range(U):
                     ca = int(pm[lane + r, j])
-                    other, l = int(rec[lane + r, j]) & 0xFFFF, int(rec[lane + r, j]) >> 16
+                    assert int(rec[lane + r, j]) & 7 == 0
+                    other, l = (int(rec[lane + r, j]) & 0xFFFF) >> 3, int(rec[lane + r, j]) >> 16
                     if ca < 0:
-                        assert l == V  # the null label
+                        if l == V + 1:  # carry record of a continuation piece: weight one, operand = the state
+                            assert r == 0 and j == 0 and other == sid and (c >> 30) & 1
+                            assert done[sid], "continuation piece before the state's first piece"
+                            terms.append(val[sid])
+                            carries += 1
+                        else:
+                            assert l == V  # the null label
                         continue
                     assert leader or r > 0 or True
                     assert lab[ca] == l
@@ -69,9 +79,7 @@ def replay(lat, b, direction, theta, extra=None):
             if leader:
                 t = np.array(terms)
                 v = -np.inf if len(t) == 0 or np.all(np.isneginf(t)) else t.max() + np.log(np.exp(t - t.max()).sum())
-                if (c >> 14) & 1:
-                    assert done[sid], "accumulate piece before the state's first piece"
-                    v = np.logaddexp(v, val[sid])
+                assert carries == ((c >> 30) & 1)
                 assert sid not in writes
                 writes[sid] = v
             else:

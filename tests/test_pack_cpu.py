@@ -92,7 +92,7 @@ def test_streams_replay_to_oracle_values(opts):
         assert lat.depth[0] >= 2 and lat.sink[0] == l.n_rows - 1
 
 
-def test_huge_degree_state_is_split_into_accumulate_pieces():
+def test_huge_degree_state_is_split_into_continuation_pieces():
     # star: 0 -bos-> 1, 1 -> {2..201} (200 arcs), all -> 202 (in-degree 200), 202 -eos-> sink 203
     V = 256
     src = [0] + [1] * 200 + list(range(2, 202)) + [202]
@@ -109,7 +109,7 @@ def test_huge_degree_state_is_split_into_accumulate_pieces():
     m = lat.meta_host[0]
     s = lat.fwd_stream.numpy().view(np.uint32)[int(m[_lib.META_FWD_OFF]):][: int(m[_lib.META_FWD_TILES]) * 128]
     ctl = s.reshape(-1, 128)[:, :64]
-    assert np.any((ctl >> 14) & 1)  # the accumulate flag is used
+    assert np.any((ctl >> 30) & 1)  # continuation pieces (carry record + flag) are used
 
 
 def test_pack_rejects_bad_lattices():
