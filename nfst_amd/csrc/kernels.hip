@@ -1515,30 +1515,28 @@ static int cu_count() {
   return n;
 }
 
-// Ring sizes per sweep from the LDS budget of one workgroup.  deep = the workgroup has a
-// CU's 160 KiB to itself (deep staging ring); otherwise two workgroups share it when the
-// lattices are small enough.  Returns R (decoded slots, kMinRing .. kMaxRing; 0 = does not
-// fit) and the staging slots in *rs.
-static int ring_slots(const LdsPlan &plan, bool fb, bool extra, bool deep, int *rs) {
+// Ring sizes per sweep from the LDS budget of one workgroup, and which kernel flavour runs.
+//   deep   (at most one lattice per CU): loader + decoder + sweep waves, deep staging ring;
+//   shared (more lattices than CUs): the decoder loads for itself, shallow staging ring, and
+//          two workgroups share a CU's 160 KiB when the lattices are small enough.
+// A lattice too large for the deep rings runs the shared flavour with the whole CU.
+struct RingCfg { int R, RS; bool self; };
+static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, RingCfg *c) {
   const int n_rings = fb ? 2 : 1;
   const int64_t slot = (int64_t)kSlotWords * 4 * n_rings;
   auto fixed = [&](int RS) { return fb ? plan.fb_bytes(0, RS, extra) : plan.bwd_bytes(0, RS, extra); };
+  auto clampr = [](int64_t r) { return (int)(r > kMaxRing ? kMaxRing : r); };
   if (deep) {
-    *rs = kRawSlotsDeep;
-    const int64_t r = (kMaxLds - fixed(*rs)) / slot;
-    if (r >= kMinRing) return (int)(r > kMaxRing ? kMaxRing : r);
-    // a very large lattice: shallow staging ring, whatever is left for the decoded ring
+    const int64_t r = (kMaxLds - fixed(kRawSlotsDeep)) / slot;
+    if (r >= kMinRing) { *c = {clampr(r), kRawSlotsDeep, false}; return true; }
   } else {
-    *rs = kRawSlotsShared;
-    const int64_t r = (kMaxLds / 2 - fixed(*rs)) / slot;
-    if (r >= kMinRing + 1) return (int)(r > kMaxRing ? kMaxRing : r);
+    const int64_t r = (kMaxLds / 2 - fixed(kRawSlotsShared)) / slot;
+    if (r >= kMinRing + 1) { *c = {clampr(r), kRawSlotsShared, true}; return true; }
   }
-  // (deep kernels run with a ring of kRawSlotsShared slots too: the loader then simply waits for
-  // the decoder earlier)
-  *rs = deep ? kDmaAheadDeep + 2 : kRawSlotsShared;
-  const int64_t r = (kMaxLds - fixed(*rs)) / slot;
-  if (r < kMinRing) return 0;
-  return (int)(r > kMaxRing ? kMaxRing : r);
+  const int64_t r = (kMaxLds - fixed(kRawSlotsShared)) / slot;
+  if (r < kMinRing) return false;
+  *c = {clampr(r), kRawSlotsShared, true};
+  return true;
 }
 
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta, double *logz64,
@@ -1548,10 +1546,9 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   if ((rc = check_scores(lat, scores))) return rc;
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
-  const bool deep = lat->n_lattices <= cu_count();
-  int RS = 0;
-  const int R = ring_slots(plan, false, extra, deep, &RS);
-  if (R == 0) return NFST_ERR_LIMIT;
+  RingCfg cfg;
+  if (!ring_config(plan, false, extra, lat->n_lattices <= cu_count(), &cfg)) return NFST_ERR_LIMIT;
+  const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.bwd_bytes(R, RS, extra);
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
   {                                                                                                    \
@@ -1559,7 +1556,8 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
     hipLaunchKernelGGL((k_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,             \
                        (hipStream_t)stream, *lat, *scores, R, RS, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
-  if (deep) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
+  // 512 threads: loader + decoder + sweep (deep); 256 threads: self-loading decoder + sweep
+  if (!cfg.self) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
   else { if (extra) NFST_LAUNCH_BWD(256, true) else NFST_LAUNCH_BWD(256, false) }
 #undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
@@ -1576,10 +1574,9 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
   const int cus = cu_count();
-  const bool deep = lat->n_lattices <= cus;
-  int RS = 0;
-  const int R = ring_slots(plan, true, extra, deep, &RS);
-  if (R == 0) return NFST_ERR_LIMIT;
+  RingCfg cfg;
+  if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
+  const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
@@ -1588,7 +1585,9 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
                        (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, posterior, \
                        grad_theta, (float2 *)beta_me);                                                  \
   }
-  if (deep) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
+  // 1024 threads: loaders + decoders + sweeps and 10 more waves for the posterior pass (deep);
+  // 512 / 256 threads: self-loading decoders + sweeps, two workgroups per CU when they fit
+  if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
   else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
   else { if (extra) NFST_LAUNCH_FB(256, true) else NFST_LAUNCH_FB(256, false) }
 #undef NFST_LAUNCH_FB

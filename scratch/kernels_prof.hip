@@ -17,7 +17,7 @@
 __device__ unsigned long long g_dbg[8192];
 extern "C" int nfst_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long)*8192); }
 namespace {
-#define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define RT(slot) do { unsigned long long r_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); if ((threadIdx.x & 63) == 0) g_dbg[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = r_; } while (0)
 
 constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -27,10 +27,13 @@ struct ME {
   int e;
 };
 
-// exp(x) = m * 2^e with m in [0.70, 1.42]; x = -inf (or below -1e30) gives zero.
+// exp(x) = m * 2^e with m in [0.70, 1.42]; x = -inf (or below -9e7) gives zero.
 __device__ __forceinline__ ME exp_split(float x) {
   ME r;
-  if (!(x > -1e30f)) { r.m = 0.0f; r.e = kEZero; return r; }
+  // weights below e^-9e7 count as zero and scores above 9e7 are clamped: exponents then
+  // stay far from the int32 range when they are added up along a path
+  if (!(x > -9.0e7f)) { r.m = 0.0f; r.e = kEZero; return r; }
+  x = fminf(x, 9.0e7f);
   float kf = rintf(x * 1.44269504088896341f);
   float t = fmaf(-kf, 0.693145751953125f, x);         // ln2 high part (exact product)
   t = fmaf(-kf, 1.42860682030941723e-6f, t);          // ln2 low part
@@ -54,7 +57,7 @@ __device__ __forceinline__ ME exp_split(float x) {
 __device__ __forceinline__ float2 me_pack(float M, int E) {
   int ex;
   float mant = frexpf(M, &ex);
-  return make_float2(mant, __int_as_float(E + ex));
+  return make_float2(mant, __int_as_float(max(E + ex, kEZero)));  // saturates at 2^(-2^28): no wrap-around
 }
 
 // natural log of an (m, e) pair in float64 / float32
@@ -135,7 +138,7 @@ struct Extra {
 //   then               (m, e) weights, slots (2k, 2k+1) of all lanes in block k (16 B per lane)
 // tiles the loader keeps in flight (HBM -> LDS by LDS-DMA) and raw-tile staging slots per
 // sweep: deep when a workgroup has a CU's LDS to itself, shallow when two share it
-constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = 6;
+constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = kDmaAheadShared + 1;
 constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
 constexpr int kRawWordsX = kRawWords + 64 * 4;  // + the slots' canonical arc ids (kernels with per-arc extras)
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
@@ -364,36 +367,31 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
   int issued = min(n_tiles, RS);  // loader_start issued these
   uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
   int freed = 0;                  // copy of the decoder's counter
-  int pub = 0;
-  unsigned long long l_begin, l_end, lw0, lw1, lwait_a = 0, lwait_b = 0, lsleeps = 0, lissues = 0; TSTAMP(l_begin);
-  while (pub < n_tiles) {
-    if (issued < n_tiles && issued - freed < RS) {
-      tile_issue<U, EXTRA>(g, perm, issued, rb, lane);
-      ++issued;
-      rb = (rb + RB == raw_end) ? raw_base : rb + RB;
-      ++lissues;
-      if (issued - pub > AHEAD) {
-        TSTAMP(lw0);
-        vm_wait<OPS * AHEAD>();
-        TSTAMP(lw1); lwait_a += lw1 - lw0;
-        pub = issued - AHEAD;
-        lds_flag_store(rland, pub);
+  int pub = 0;                    // tiles published in rland
+  auto publish_oldest = [&]() {
+    wait_tiles_in_flight<OPS, AHEAD>(issued - pub - 1);
+    ++pub;
+    lds_flag_store(rland, pub);
+  };
+  while (issued < n_tiles) {
+    if (__builtin_expect(issued - freed >= RS, 0)) {  // ring full: look at the decoder's progress
+      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (issued - freed >= RS) {
+        if (pub < issued) publish_oldest();
+        else __builtin_amdgcn_s_sleep(1);
       }
       continue;
     }
-    if (pub < issued) {  // nothing to issue right now: publish the oldest tile in flight
-      TSTAMP(lw0);
-      wait_tiles_in_flight<OPS, AHEAD>(issued - pub - 1);
-      TSTAMP(lw1); lwait_b += lw1 - lw0;
-      ++pub;
+    tile_issue<U, EXTRA>(g, perm, issued, rb, lane);
+    ++issued;
+    rb = (rb + RB == raw_end) ? raw_base : rb + RB;
+    if (issued - pub > AHEAD) {
+      vm_wait<OPS * AHEAD>();
+      pub = issued - AHEAD;
       lds_flag_store(rland, pub);
     }
-    if (issued < n_tiles) {
-      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
-      if (pub == issued && issued - freed >= RS) { ++lsleeps; __builtin_amdgcn_s_sleep(1); }
-    }
   }
-  TSTAMP(l_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = l_end - l_begin; o[1] = lwait_a; o[2] = lwait_b; o[3] = n_tiles; o[4] = lsleeps; o[5] = lissues; }
+  while (pub < n_tiles) publish_oldest();
 }
 
 // ---- decoder wave -----------------------------------------------------------------
@@ -431,11 +429,37 @@ __device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<U, EXTR
   }
 }
 
-template <int U, bool EXTRA>
+// SELF: the decoder also does the loader's job (kernels with two workgroups per CU run
+// fewer, busier waves): it keeps AHEAD tiles in flight itself -- self_start() at kernel
+// entry, one issue per iteration -- and a counted wait replaces the rland flag.  The
+// staging ring then has AHEAD + 1 slots.
+template <int U, bool EXTRA, int AHEAD>
+__device__ __forceinline__ void self_start_u(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int lane) {
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw);
+  const int last = max(n_tiles - 1, 0);
+#pragma unroll
+  for (int d = 0; d < AHEAD; ++d)  // short programs copy their last tile again: the count stays constant
+    tile_issue<U, EXTRA>(g, perm, min(d, last), raw_base + d * RB, lane);
+}
+template <bool EXTRA, int AHEAD>
+__device__ __forceinline__ void self_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
+                                           int lane) {
+  if (U == 4) self_start_u<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  else if (U == 2) self_start_u<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  else self_start_u<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+}
+
+template <int U, bool EXTRA, bool SELF, int AHEAD>
 __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, int RS, const int *rland,
+                                             const uint32_t *g, const int32_t *perm,
                                              uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
                                              const float2 *th_, const Extra ex, int lane) {
-  if (n_tiles <= 0) return;
+  if (n_tiles <= 0) {
+    if (SELF) vm_wait<0>();
+    return;
+  }
+  constexpr int OPS = DmaOps<U, EXTRA>::value;
   constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
   constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
   const uint32_t th_base = lds_addr(th_);
@@ -444,26 +468,36 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
   const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
   uint32_t sb = ring_base;  // decoded slot of tile t
   uint32_t rb = raw_base;   // staging slot of the tile whose raw words are fetched next
+  uint32_t rb_issue = raw_base + (SELF ? AHEAD * RB : 0);  // SELF: staging slot of the tile issued next
+  int issue_next = AHEAD;                                   // SELF: that tile
+  const int last = n_tiles - 1;
   int freed = 0, landed = 0;
-  unsigned long long d_begin, d_end, dw0, dw1, dwaited = 0, dpolls = 0, lwaited = 0; TSTAMP(d_begin);
+  // makes sure the raw words of tile need-1 are in the staging ring (called once per tile, in order)
   auto wait_raw = [&](int need) {
-    if (landed < need) { TSTAMP(dw0);
+    if (SELF) {
+      // one more tile goes in flight (past the end the last tile is copied again into a slot
+      // nobody reads, so that the count stays exact); then at most AHEAD are
+      tile_issue<U, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
+      ++issue_next;
+      rb_issue = (rb_issue + RB == raw_end) ? raw_base : rb_issue + RB;
+      vm_wait<OPS * AHEAD>();
+      return;
+    }
     while (__builtin_expect(landed < need, 0)) {
       landed = __builtin_amdgcn_readfirstlane(lds_flag_load(rland));
       if (landed < need) __builtin_amdgcn_s_sleep(1);
     }
-    TSTAMP(dw1); lwaited += dw1 - dw0; }
     asm volatile("" ::: "memory");
   };
-  RawRegs<U, EXTRA> cur, nxt;
-  wait_raw(1);
-  raw_fetch<U, EXTRA>(rb, lane, cur);
-  for (int t = 0; t < n_tiles; ++t) {
-    // --- label weights of tile t (LDS gathers), then the raw words of tile t+1 in their
-    // shadow; past the end this reads a stale staging slot whose contents are never used
-    v2f tw[U];
+  auto gather_weights = [&](const RawRegs<U, EXTRA> &w, v2f (&tw)[U]) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + ((cur.rc[j] >> 16) << 3));
+    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + ((w.rc[j] >> 16) << 3));
+  };
+  // iteration t: `cur` = raw words of tile t, `tw` = its label weights (LDS gathers issued
+  // one iteration earlier); fetches the raw words of tile t+1 into `nxt` and, at the end,
+  // issues the gathers of its label weights into `twn`
+  auto step = [&](int t, const RawRegs<U, EXTRA> &cur, v2f (&tw)[U], RawRegs<U, EXTRA> &nxt, v2f (&twn)[U]) {
+    // past the end this reads a stale staging slot whose contents are never used
     rb = (rb + RB == raw_end) ? raw_base : rb + RB;
     wait_raw(min(t + 2, n_tiles));
     raw_fetch<U, EXTRA>(rb, lane, nxt);
@@ -474,14 +508,9 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 #pragma unroll
     for (int j = 0; j < U; ++j) oa[j] = (cur.rc[j] & 0xffffu) + val_base;
     // --- the ring slot must be free: tile t - R consumed
-    if (__builtin_expect(t - freed >= R, 0)) {
-      TSTAMP(dw0);
-      while (t - freed >= R) {
-        freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
-        ++dpolls;
-        if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
-      }
-      TSTAMP(dw1); dwaited += dw1 - dw0;
+    while (__builtin_expect(t - freed >= R, 0)) {
+      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
+      if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
     *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
@@ -509,13 +538,24 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
       *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = tw[0];
     }
     asm volatile("" ::: "memory");
-    // tile t is decoded; the loader reads the same word: the raw words of tiles 0 .. t are
-    // in registers (tile t+1's may still be on their way: the loader keeps one slot clear)
+    // tile t is decoded; the loader reads the same word: the raw words of tiles 0 .. t+1
+    // are in registers
     lds_flag_store(land, t + 1);
     sb = (sb + SB == ring_end) ? ring_base : sb + SB;
-    cur = nxt;
+    gather_weights(nxt, twn);
+  };
+  RawRegs<U, EXTRA> ra, rbb;
+  v2f ta[U], tb[U];
+  wait_raw(1);
+  raw_fetch<U, EXTRA>(rb, lane, ra);
+  gather_weights(ra, ta);
+  // two iterations per trip so that the register roles alternate without copies
+  for (int t = 0; t < n_tiles; t += 2) {
+    step(t, ra, ta, rbb, tb);
+    if (t + 1 >= n_tiles) break;
+    step(t + 1, rbb, tb, ra, ta);
   }
-  TSTAMP(d_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = d_end - d_begin; o[1] = dwaited; o[2] = dpolls; o[3] = n_tiles; o[4] = lwaited; }
+  if (SELF) vm_wait<0>();  // nothing of the staging ring stays in flight
 }
 
 // decoded tile in the sweep wave's registers
@@ -559,17 +599,11 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   if (n_tiles <= 0) return;
   constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;  // bytes per ring slot
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
-  unsigned long long t_begin, t_end, tw0, tw1, waited = 0, polls = 0; TSTAMP(t_begin);
   int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
   auto wait_landed = [&](int need) {
-    if (__builtin_expect(landed < need, 0)) {
-      TSTAMP(tw0);
-      while (landed < need) {
-        landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
-        ++polls;
-        if (landed < need) __builtin_amdgcn_s_sleep(1);
-      }
-      TSTAMP(tw1); waited += tw1 - tw0;
+    while (__builtin_expect(landed < need, 0)) {
+      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (landed < need) __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
   };
@@ -646,12 +680,11 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
     if (T + 1 >= n_tiles) break;
     step(T + 1, db, cb, da, ca, true);
   }
-  TSTAMP(t_end); if (lane == 0 && blockIdx.x == 7) { unsigned long long *o = g_dbg + (threadIdx.x >> 6) * 16; o[0] = t_end - t_begin; o[1] = waited; o[2] = polls; o[3] = n_tiles; }
 }
 
 // role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder.
 // flags: [0] prog [1] land [2] rland
-template <bool EXTRA, int AHEAD>
+template <bool EXTRA, bool SELF, int AHEAD>
 __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *raw, int RS, const uint32_t *g,
                                           const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
                                           float2 *val, const float2 *th, const Extra ex, int lane) {
@@ -667,10 +700,10 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
       else tile_sweep<1, false>(n_tiles, ring, R, prog, land, lane);
     }
   } else if (role == 1) {
-    if (U == 4) tile_decoder<4, EXTRA>(n_tiles, raw, RS, rland, ring, R, prog, land, val, th, ex, lane);
-    else if (U == 2) tile_decoder<2, EXTRA>(n_tiles, raw, RS, rland, ring, R, prog, land, val, th, ex, lane);
-    else tile_decoder<1, EXTRA>(n_tiles, raw, RS, rland, ring, R, prog, land, val, th, ex, lane);
-  } else {
+    if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 2) tile_decoder<2, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    else tile_decoder<1, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+  } else if (!SELF) {
     if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
     else if (U == 2) tile_loader<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
     else tile_loader<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
@@ -730,8 +763,15 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t *raw = ring + (size_t)R * kSlotWords;
-  if (wv == 2)
+  // NT = 512: the workgroup has the CU to itself: wave 2 loads for the decoder (deep staging
+  // ring); NT = 256: two workgroups per CU, the decoder loads for itself
+  constexpr bool kSelf = NT != 512;
+  constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
+  if (kSelf) {
+    if (wv == 1) self_start<EXTRA, kAhead>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, raw, lane);
+  } else if (wv == 2) {
     loader_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, raw, RS, lane);
+  }
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
   __syncthreads();
@@ -741,8 +781,8 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
     flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
   }
   __syncthreads();
-  if (wv < 3)
-    run_sweep<EXTRA, (NT == 512 ? kDmaAheadDeep : kDmaAheadShared)>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
+  if (wv < (kSelf ? 2 : 3))
+    run_sweep<EXTRA, kSelf, kAhead>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
               m.bwd_tiles, ring, R, flags, beta, th, ex, lane);
   __syncthreads();
   if (tid == 0) {
@@ -780,6 +820,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
+  RT(0);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
@@ -800,7 +841,15 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   const bool my_wide = (bwd_side ? m.bwd_wide : m.fwd_wide) != 0;
   uint32_t *my_ring = bwd_side ? ring : ring + LdsPlan::sweep_words(R, RS, EXTRA);
   uint32_t *my_raw = my_ring + (size_t)R * kSlotWords;
-  if (wv == 4 || wv == 5) loader_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, my_raw, RS, lane);
+  // NT = 1024: the workgroup has the CU to itself: waves 4 / 5 load for the decoders (deep
+  // staging ring); otherwise two workgroups share a CU and the decoders load for themselves
+  constexpr bool kSelf = NT != 1024;
+  constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
+  if (kSelf) {
+    if (wv == 2 || wv == 3) self_start<EXTRA, kAhead>(my_u, my_prog, my_perm, my_tiles, my_raw, lane);
+  } else if (wv == 4 || wv == 5) {
+    loader_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, my_raw, RS, lane);
+  }
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -839,11 +888,13 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       }
     }
   }
-  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 4 / 5 load for them
-  if (wv < 6)
-    run_sweep<EXTRA, (NT == 1024 ? kDmaAheadDeep : kDmaAheadShared)>(wv >> 1, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
+  RT(1);
+  if (wv < (kSelf ? 4 : 6))
+    run_sweep<EXTRA, kSelf, kAhead>(wv >> 1, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
                      bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex, lane);
+  RT(2);
   __syncthreads();
+  RT(3);
   const float2 zme = beta[0];
   if (tid == 0) {
     const double z = me_log64(zme);
@@ -917,6 +968,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       for (int l = tid; l < lat.vocab; l += NT) gout[l] = gth[l];
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RT(4);
 }
 
 // ------------------------------------------------------------------ Viterbi
@@ -1545,7 +1598,7 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   }
   if (deep) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
   else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
-  else { if (extra) NFST_LAUNCH_FB(384, true) else NFST_LAUNCH_FB(384, false) }
+  else { if (extra) NFST_LAUNCH_FB(256, true) else NFST_LAUNCH_FB(256, false) }
 #undef NFST_LAUNCH_FB
   return hip_status(hipGetLastError());
 }

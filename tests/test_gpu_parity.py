@@ -354,3 +354,47 @@ def test_path_logprob_matches_oracle_all_variants(dev, V, T):
         fin = np.isfinite(ref)
         assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
         assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) <= 2e-5
+
+def test_large_lattice_falls_back_to_small_rings(dev):
+    """A lattice close to the LDS limit (alpha + beta = 16 B per state of the CU's 160 KiB) leaves
+    room for the smallest rings only (3 decoded + 5 staging slots, self-loading decoder)."""
+    V = 256
+    big = synth.layered_lattice(3, n_states=7800, avg_degree=6.0, vocab=V, width=32, span=4)
+    small = synth.layered_lattice(4, n_states=300, avg_degree=6.0, vocab=V, width=8, span=4)
+    theta = synth.label_scores(5, V)
+    lat = LatticeBatch.from_synth([big, small], device=dev)
+    assert lat.lds_bytes() <= 160 * 1024
+    r = ops.forward_backward(lat, torch.from_numpy(theta))
+    rb = ops.backward(lat, torch.from_numpy(theta))
+    for b, l in enumerate([big, small]):
+        o, _ = oracle_fb(l, theta)
+        r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
+        assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL * max(1.0, abs(o["logZ"]) / 16)
+        assert abs(float(rb.logz64[b]) - o["logZ"]) <= TOL * max(1.0, abs(o["logZ"]) / 16)
+        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tol=TOL * max(1.0, abs(o["logZ"]) / 16))
+        assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 5e-6
+    # beyond the limit the launch is refused with an error code, not a fault
+    huge = synth.layered_lattice(6, n_states=8180, avg_degree=4.0, vocab=V, width=32, span=4)
+    lat = LatticeBatch.from_synth([huge], device=dev)
+    with pytest.raises(_lib.NfstError) as e:
+        ops.forward_backward(lat, torch.from_numpy(theta))
+    assert e.value.code == -6  # NFST_ERR_LIMIT
+
+
+def test_huge_negative_scores_saturate_instead_of_wrapping(dev):
+    """Scores like -1e9 (a common "mask" value) must behave as zero weights: their exponents,
+    added up along a path, would leave the int32 range."""
+    l = synth.layered_lattice(21, n_states=300, avg_degree=8.0, vocab=64, width=8, span=4)
+    theta = synth.label_scores(3, 64)
+    masked = np.unique(l.label)[::7]
+    masked = masked[(masked != BOS) & (masked != EOS)]
+    for v in (-1e9, -3e38):
+        th = theta.copy()
+        th[masked] = v
+        ref = theta.copy()
+        ref[masked] = -np.inf
+        r = ops.forward_backward(LatticeBatch.from_synth([l], device=dev), torch.from_numpy(th.astype(np.float32)))
+        o, _ = oracle_fb(l, ref)
+        assert np.isfinite(o["logZ"])
+        assert abs(float(r.logz64[0]) - o["logZ"]) <= TOL
+        assert np.max(np.abs(r.posterior.cpu().numpy() - o["posterior"])) <= 2e-6
