@@ -141,8 +141,9 @@ typedef struct nfst_packed nfst_packed; /* opaque, owns host arrays */
 /* pack options; zero-initialise for defaults */
 typedef struct nfst_pack_opts {
   int32_t n_threads;       /* host threads over lattices (0 = hardware) */
-  int32_t slots_per_lane;  /* arc slots per lane of a tile: 1, 2 or 4 (0 = per lattice, fewest tiles) */
-  int32_t reserved0;
+  int32_t slots_per_lane;  /* arc slots per lane of a tile: 1, 2 or 4 (0 = per lattice and direction, cheapest) */
+  int32_t group_mode;      /* largest lane group of a state: 1 = narrow (8 lanes, more tiles for high-degree
+                              states), 2 = wide (64 lanes), 0 = per lattice and direction, cheapest */
   int32_t reserved1;
 } nfst_pack_opts;
 

@@ -49,7 +49,7 @@ class Scores(C.Structure):
 
 
 class PackOpts(C.Structure):
-    _fields_ = [("n_threads", C.c_int32), ("slots_per_lane", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("n_threads", C.c_int32), ("slots_per_lane", C.c_int32), ("group_mode", C.c_int32),
                 ("reserved1", C.c_int32)]
 
 

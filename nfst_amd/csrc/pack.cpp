@@ -23,6 +23,7 @@ namespace {
 struct Opts {
   int n_threads = 0;
   int slots_per_lane = 0;  // 0 = choose per lattice and direction
+  int group_mode = 0;      // 0 = choose, 1 = narrow, 2 = wide
 };
 
 struct Lat {
@@ -212,12 +213,13 @@ void schedule(Lat &L, int vocab, const Opts &o) {
     for (int q = 0; q < 3; ++q) {
       if ((o.slots_per_lane == 1 || o.slots_per_lane == 2 || o.slots_per_lane == 4) && us[q] != o.slots_per_lane) continue;
       for (int wide = 0; wide < 2; ++wide) {
+        if ((o.group_mode == 1 && wide) || (o.group_mode == 2 && !wide)) continue;
         TileCount c;
         for (int t = 1; t <= D; ++t) {
           if (backward) emit_level(by_height[t], us[q], wide ? 6 : 3, null_label, out_of, dst_of, out_list, L.label, nullptr, nullptr, c);
           else emit_level(by_depth[t], us[q], wide ? 6 : 3, null_label, in_of, src_of, in_list, L.label, nullptr, nullptr, c);
         }
-        if (wide && c.wide == 0) continue;  // same program as the narrow one
+        if (wide && c.wide == 0 && o.group_mode != 2) continue;  // same program as the narrow one
         const double cost = (double)c.tiles * (330.0 + 55.0 * us[q] + (wide ? 60.0 : 0.0)) + 450.0 * c.wide;
         if (!have || cost < best) { have = true; best = cost; u_out = us[q]; wide_out = wide; }
       }
@@ -252,6 +254,7 @@ Opts read_opts(const nfst_pack_opts *o) {
   if (o) {
     r.n_threads = o->n_threads;
     r.slots_per_lane = o->slots_per_lane;
+    r.group_mode = o->group_mode;
   }
   return r;
 }

@@ -31,7 +31,7 @@ for name in ("fetch", "write"):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         out[k] = {"mean_per_dispatch_KiB": sum(v) / len(v), "dispatches": len(v)}
-out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 50 --warmup 10`; "
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 50 --warmup 10; "
                "values in KiB per k_forward_backward dispatch; gfx950 FETCH_SIZE counts 64 B per 128-B streaming request")
 json.dump(out, open("$R/gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
