@@ -398,3 +398,80 @@ def test_huge_negative_scores_saturate_instead_of_wrapping(dev):
         assert np.isfinite(o["logZ"])
         assert abs(float(r.logz64[0]) - o["logZ"]) <= TOL
         assert np.max(np.abs(r.posterior.cpu().numpy() - o["posterior"])) <= 2e-6
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_shapes_match_oracle(dev, seed):
+    """Ragged batches of random shapes: chains, wide and narrow layers, high degrees (continuation
+    pieces and wide groups), tiny lattices whose whole program is shorter than the rings."""
+    rng = np.random.default_rng(100 + seed)
+    V = int(rng.choice([96, 300]))
+    lats = []
+    for i in range(24):
+        n = int(rng.choice([4, 5, 17, 60, 200, 700, 1500]))
+        width = int(rng.choice([1, 2, 4, 16, 48] if V > 100 else [1, 2, 4, 16]))
+        deg = float(rng.choice([1.5, 4.0, 10.0, 40.0] if V > 100 else [1.5, 4.0, 10.0]))
+        lats.append(synth.layered_lattice(1000 * seed + i, n_states=n, avg_degree=min(deg, V - 4), vocab=V, width=width,
+                                          span=int(rng.choice([1, 3, 8])), max_degree=min(V - 4, 64)))
+    lats.append(synth._finish(2, V, [0], [EOS], [1]))
+    theta = synth.label_scores(seed, V, mean=float(rng.choice([-2.0, 0.5])), std=1.0)
+    for opts in (dict(), dict(group_mode=1), dict(group_mode=2, slots_per_lane=int(rng.choice([1, 2, 4])))):
+        lat = LatticeBatch.from_synth(lats, device=dev, **opts)
+        r = ops.forward_backward(lat, torch.from_numpy(theta))
+        la, lb, post = r.logalpha.cpu().numpy(), r.logbeta.cpu().numpy(), r.posterior.cpu().numpy()
+        for b, l in enumerate(lats):
+            o, _ = oracle_fb(l, theta)
+            tol = TOL * max(1.0, abs(o["logZ"]) / 16)
+            r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
+            assert abs(float(r.logz64[b]) - o["logZ"]) <= tol
+            cmp_rows(la[r0:r0 + l.n_rows], o["logalpha"], tol)
+            cmp_rows(lb[r0:r0 + l.n_rows], o["logbeta"], tol)
+            # float32 rounding accumulates over the levels (up to 1500 here): 1e-5 instead of the
+            # 2e-6 that holds at the BASELINE depth
+            assert np.max(np.abs(post[a0:a0 + l.n_arcs] - o["posterior"])) <= 1e-5
+
+
+def test_many_small_lattices_share_compute_units(dev):
+    """More lattices than CUs: the 512- and 256-thread flavours (decoder loads for itself, two
+    workgroups per CU) must give the same bits as the one-lattice-per-CU flavour."""
+    V = 64
+    base = [synth.layered_lattice(7000 + i, n_states=40 + 13 * (i % 9), avg_degree=5.0, vocab=V, width=1 + i % 7, span=3)
+            for i in range(40)]
+    theta = torch.from_numpy(synth.label_scores(9, V))
+    ref = ops.forward_backward(LatticeBatch.from_synth(base, device=dev), theta)
+    for reps in (8, 15):  # 320 and 600 lattices
+        lat = LatticeBatch.from_synth(base * reps, device=dev)
+        r = ops.forward_backward(lat, theta)
+        rb = ops.backward(lat, theta)
+        z = r.logz64.view(reps, len(base))
+        assert torch.equal(z, ref.logz64.expand(reps, -1))
+        assert torch.equal(rb.logz64, r.logz64)
+        assert torch.equal(r.posterior.view(reps, -1), ref.posterior.expand(reps, -1))
+        assert torch.equal(r.logbeta.view(reps, -1), ref.logbeta.expand(reps, -1))
+
+
+def test_forward_backward_is_graph_capturable(dev):
+    """The launch allocates nothing and keeps no state: after one warm-up call it can be captured
+    in a HIP graph and replayed."""
+    lats = _mixed_batch()
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    theta = torch.from_numpy(synth.label_scores(7, 64)).to(dev)
+    out = ops.forward_backward(lat, theta)           # warm-up: sets the LDS attribute, allocates outputs
+    ref_z, ref_p = out.logz64.clone(), out.posterior.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            out = ops.forward_backward(lat, theta, out=out)
+    torch.cuda.current_stream().wait_stream(s)
+    theta2 = theta.clone()
+    for scale in (1.0, 0.5):
+        theta.copy_(theta2 * scale)
+        out.logz64.zero_(); out.posterior.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        chk = ops.forward_backward(lat, theta)
+        assert torch.equal(out.logz64, chk.logz64) and torch.equal(out.posterior, chk.posterior)
+    theta.copy_(theta2)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out.logz64, ref_z) and torch.equal(out.posterior, ref_p)
