@@ -285,12 +285,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // does not put s_waitcnt vmcnt(0) in front of every LDS access; the counted waits are
 // placed by hand (vm_wait).  In-flight data never lives in registers, so no compiler-made
 // register copy can touch it early.  Only full-wave 4- and 16-byte forms are used (the
-// 12-byte and exec-masked forms do not lay lanes out at lane x size on gfx950).
+// 12-byte and exec-masked forms do not lay lanes out at lane x size on gfx950).  `nt`: a tile
+// program is read once per launch by one CU (measured: 1-2 % on the whole step).
 __device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
 }
 __device__ __forceinline__ void lds_dma4(const void *gsrc, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait() {  // at most N vector-memory operations of this wave stay in flight
@@ -365,16 +366,19 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
   uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
   int freed = 0;                  // copy of the decoder's counter
   int pub = 0;                    // tiles published in rland
-  auto publish_oldest = [&]() {
-    wait_tiles_in_flight<OPS, AHEAD>(issued - pub - 1);
-    ++pub;
+  // nothing to issue right now: wait until half of the unpublished tiles have landed and
+  // publish those (then half of the rest, ...)
+  auto publish_some = [&]() {
+    const int keep = (issued - pub - 1) >> 1;  // tiles that may stay in flight
+    wait_tiles_in_flight<OPS, AHEAD>(keep);
+    pub = issued - keep;
     lds_flag_store(rland, pub);
   };
   while (issued < n_tiles) {
     if (__builtin_expect(issued - freed >= RS, 0)) {  // ring full: look at the decoder's progress
       freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
       if (issued - freed >= RS) {
-        if (pub < issued) publish_oldest();
+        if (pub < issued) publish_some();
         else __builtin_amdgcn_s_sleep(1);
       }
       continue;
@@ -388,7 +392,7 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
       lds_flag_store(rland, pub);
     }
   }
-  while (pub < n_tiles) publish_oldest();
+  while (pub < n_tiles) publish_some();
 }
 
 // ---- decoder wave -----------------------------------------------------------------
@@ -661,7 +665,7 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
       }
     }
     // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
-    if (publish) lds_flag_store(prog, T + 2);
+    if (publish || R < 6) lds_flag_store(prog, T + 2);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (WIDE) cu_nxt = (uint32_t)__builtin_amdgcn_readfirstlane(nxt.w0);
@@ -828,7 +832,9 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   constexpr bool has_extra = EXTRA;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // waves 0 / 2 / 4: beta sweep, its decoder and its loader; waves 1 / 3 / 5: the same for alpha
+  // even waves work for the beta sweep, odd waves for alpha: waves 0 / 1 sweep, 2 / 3 decode,
+  // 6 / 7 load (waves i, i+4, ... share a SIMD: the busy-polling loaders sit with the decoders,
+  // the sweep waves share theirs only with waves that sleep at the barrier)
   const bool bwd_side = (wv & 1) == 0;
   const uint32_t *my_prog = bwd_side ? lat.bwd_stream + m.bwd_off : lat.fwd_stream + m.fwd_off;
   const int32_t *my_perm = bwd_side ? lat.bwd_perm + m.bwd_slot_off : lat.fwd_perm + m.fwd_slot_off;
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
   if (kSelf) {
     if (wv == 2 || wv == 3) self_start<EXTRA, kAhead>(my_u, my_prog, my_perm, my_tiles, my_raw, lane);
-  } else if (wv == 4 || wv == 5) {
+  } else if (wv == 6 || wv == 7) {
     loader_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, my_raw, RS, lane);
   }
   for (int i = tid; i < m.n_rows; i += NT) {
@@ -884,9 +890,9 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       }
     }
   }
-  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 4 / 5 load for them
-  if (wv < (kSelf ? 4 : 6))
-    run_sweep<EXTRA, kSelf, kAhead>(wv >> 1, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 6 / 7 load for them
+  if (wv < 4 || (!kSelf && (wv == 6 || wv == 7)))
+    run_sweep<EXTRA, kSelf, kAhead>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
                      bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex, lane);
   __syncthreads();
   const float2 zme = beta[0];
@@ -965,81 +971,160 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
 }
 
 // ------------------------------------------------------------------ Viterbi
-// max-plus run of the by-source tile program by one wave (float32 values, canonical
-// arc back pointers in LDS; the program is read straight from global memory -- this
-// kernel is not on the benchmark path), then lane 0 walks the best path.  Ties keep
-// the arc with the smallest canonical id, i.e. the smallest label.
-__device__ __forceinline__ void vit_take(float &bv, int &ba, float ov, int oa) {
-  if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; }
+// max-plus run of the by-source tile program by one wave (float32 values, back pointers
+// -- canonical arc and next state -- in LDS; the program is read straight from global
+// memory), then lane 0 walks the best path inside LDS.  Ties keep the arc with the smallest
+// canonical id, i.e. the smallest label.
+__device__ __forceinline__ void vit_take(float &bv, int &ba, int &bn, float ov, int oa, int on) {
+  if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; bn = on; }  // bn: the arc's other end
 }
 
-__global__ __launch_bounds__(64) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
-                                                int32_t *paths, int32_t *path_arcs,
-                                                int32_t *lengths, int max_len, int pad) {
+// Wave 0 runs the program; waves 1 .. 3 run ahead of it and pull the tiles it will read
+// (program words, slot -> arc map, per-arc extras) into the L2 cache, throttled by wave 0's
+// progress counter in LDS, so that its dependent loads are L2 hits instead of HBM misses.
+constexpr int kVitThreads = 256, kVitAhead = 12;
+__global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
+                                                         int32_t *paths, int32_t *path_arcs,
+                                                         int32_t *lengths, int max_len, int pad) {
   extern __shared__ float2 lds[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
   float *v = (float *)lds;
-  int *bp = (int *)(v + lat.max_rows);
-  for (int i = lane; i < m.n_rows; i += 64) { v[i] = kNegInf; bp[i] = -1; }
-  __syncthreads();
-  if (lane == 0) v[m.sink] = 0.0f;
-  __syncthreads();
+  int *bp = (int *)(v + lat.max_rows);       // back pointer: best arc out of the state
+  int *ns = bp + lat.max_rows;               // ... and the state it leads to
+  float *tl = (float *)(ns + lat.max_rows);  // [V] label scores
+  int *progress = (int *)(tl + lat.vocab);
   const float *tg = sc.theta + (size_t)sc.theta_stride * b;
+  for (int i = tid; i < m.n_rows; i += kVitThreads) { v[i] = kNegInf; bp[i] = -1; }
+  for (int i = tid; i < lat.vocab; i += kVitThreads) tl[i] = tg[i];
+  if (tid == 0) *progress = 0;
+  __syncthreads();
+  if (tid == 0) v[m.sink] = 0.0f;
+  __syncthreads();
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
   const int U = m.bwd_u, ST = 64 * (1 + U);
   const uint32_t *prog = lat.bwd_stream + m.bwd_off;
   const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
   constexpr int kNone = 0x7fffffff;
+  if (wv > 0) {
+    const bool extras = arc_w != nullptr || sc.arc_scores != nullptr;
+    float sink_f = 0.0f;
+    int sink_i = 0;
+    for (int T = wv - 1; T < m.bwd_tiles; T += kVitThreads / 64 - 1) {
+      while (T > lds_flag_load(progress) + kVitAhead) __builtin_amdgcn_s_sleep(8);
+      // one 128-byte line per lane
+      const int prog_lines = (ST * 4 + 127) / 128, perm_lines = (64 * U * 4 + 127) / 128;
+      if (lane < prog_lines) sink_i += (int)prog[(size_t)T * ST + min(lane * 32, ST - 1)];
+      if (!extras) {
+        if (lane < perm_lines) sink_i += perm[(size_t)T * 64 * U + min(lane * 32, 64 * U - 1)];
+      } else {
+        for (int j = 0; j < U; ++j) {
+          const int ca = perm[(size_t)T * 64 * U + lane * U + j];
+          if (ca >= 0) {
+            if (arc_w) sink_f += arc_w[ca];
+            if (sc.arc_scores) sink_f += sc.arc_scores[ca];
+          }
+        }
+      }
+    }
+    if (sink_f == 1.2345e-33f && sink_i == 0x12345678) best[b] = 0.0f;  // keeps the loads alive, never true
+  } else {
+  // the words of tile T+1 are loaded while tile T is computed
+  struct VitTile { uint32_t ctl; int cas[4]; uint32_t rcs[4]; };
+  auto load_tile = [&](int T, VitTile &t) {
+    t.ctl = prog[(size_t)T * ST + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jj = min(j, U - 1);
+      t.cas[j] = perm[(size_t)T * 64 * U + lane * U + jj];
+      t.rcs[j] = prog[(size_t)T * ST + 64 + lane * U + jj];
+    }
+  };
+  VitTile cur, nxt;
+  if (m.bwd_tiles > 0) load_tile(0, cur);
   for (int T = 0; T < m.bwd_tiles; ++T) {
-    const uint32_t ctl = prog[(size_t)T * ST + lane];
+    load_tile(min(T + 1, m.bwd_tiles - 1), nxt);
+    const uint32_t ctl = cur.ctl;
+    int cas[4];
+    uint32_t rcs[4];
+    float xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cas[j] = (j < U) ? cur.cas[j] : -1; rcs[j] = cur.rcs[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xs[j] = 0.0f;
+      if (cas[j] >= 0) {
+        if (arc_w) xs[j] += arc_w[cas[j]];
+        if (sc.arc_scores) xs[j] += sc.arc_scores[cas[j]];
+      }
+    }
     float bv = kNegInf;
-    int ba = kNone;
-    for (int j = 0; j < U; ++j) {
-      const int ca = perm[(size_t)T * 64 * U + lane * U + j];
-      if (ca < 0) continue;
-      const uint32_t rc = prog[(size_t)T * ST + 64 + lane * U + j];
-      float s0 = tg[rc >> 16];
-      if (arc_w) s0 += arc_w[ca];
-      if (sc.arc_scores) s0 += sc.arc_scores[ca];
-      vit_take(bv, ba, s0 + v[(rc & 0xffffu) >> 3], ca);
+    int ba = kNone, bn = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int other = (int)((rcs[j] & 0xffffu) >> 3);
+      if (cas[j] >= 0) vit_take(bv, ba, bn, tl[rcs[j] >> 16] + xs[j] + v[other], cas[j], other);
     }
     const int gl = (int)((ctl >> 20) & 7u);
-    for (int st = 0; st < 6; ++st) {
-      int partner;
-      if (st == 0) partner = lane ^ 1;
-      else if (st == 1) partner = lane ^ 2;
-      else if (st == 2) partner = (lane & ~7) | (7 - (lane & 7));
-      else if (st == 3) partner = (lane & ~15) | (15 - (lane & 15));
-      else partner = lane ^ (1 << st);
-      const float ov = __shfl(bv, partner);
-      const int oa = __shfl(ba, partner);
-      if (gl > st) vit_take(bv, ba, ov, oa);
+    const int gmax = (int)((__builtin_amdgcn_readfirstlane(ctl) >> 23) & 7u);
+    // segmented max over the state's lanes: quad permutes and row mirrors (DPP), then the
+    // two cross-row stages; every lane of a state ends with the same (value, arc, next state)
+#define NFST_VIT_STAGE(ST, FV, FI)                                          \
+    if (gmax > ST) {                                                        \
+      const float ov = FV(bv);                                              \
+      const int oa = FI(ba), on = FI(bn);                                   \
+      if (gl > ST) vit_take(bv, ba, bn, ov, oa, on);                        \
     }
+#define NFST_SHFL16(x) __shfl_xor(x, 16)
+#define NFST_SHFL32(x) __shfl_xor(x, 32)
+    NFST_VIT_STAGE(0, dpp_f<0xB1>, dpp_i<0xB1>)
+    NFST_VIT_STAGE(1, dpp_f<0x4E>, dpp_i<0x4E>)
+    NFST_VIT_STAGE(2, dpp_f<0x141>, dpp_i<0x141>)
+    NFST_VIT_STAGE(3, dpp_f<0x140>, dpp_i<0x140>)
+    NFST_VIT_STAGE(4, NFST_SHFL16, NFST_SHFL16)
+    NFST_VIT_STAGE(5, NFST_SHFL32, NFST_SHFL32)
+#undef NFST_VIT_STAGE
+#undef NFST_SHFL16
+#undef NFST_SHFL32
     if (ctl & (1u << 31)) {
       const uint32_t sid = (ctl & 0xffffu) >> 3;
-      if ((ctl & (1u << 30)) && bp[sid] >= 0) vit_take(bv, ba, v[sid], bp[sid]);
+      if ((ctl & (1u << 30)) && bp[sid] >= 0) vit_take(bv, ba, bn, v[sid], bp[sid], ns[sid]);
       v[sid] = bv;
       bp[sid] = (ba == kNone) ? -1 : ba;
+      ns[sid] = bn;
     }
-    __syncthreads();  // single wave: orders the LDS stores before the next tile's loads
+    // LDS accesses of one wave execute in order: the next tile's loads see these stores
+    asm volatile("" ::: "memory");
+    if ((T & 3) == 3) lds_flag_store(progress, T);
+    cur = nxt;
   }
-  if (lane == 0) {
+  }
+  // lane 0 walks the back pointers inside LDS (arc ids go to the list `pa`, which reuses the
+  // value array); all threads then write the labels
+  int *pa = (int *)v;
+  int *res = progress;  // [0] length, [1] reached the sink
+  if (tid == 0) {
     best[b] = v[0];
     int s0 = 0, len = 0;
-    while (s0 != m.sink && len < max_len) {
+    const int cap = min(max_len, m.n_rows);
+    while (s0 != m.sink && len < cap) {
       const int a = bp[s0];
       if (a < 0) break;
-      paths[(size_t)b * max_len + len] = lat.arc_label[a];
-      if (path_arcs) path_arcs[(size_t)b * max_len + len] = a;
-      ++len;
-      s0 = lat.arc_dst[a];
+      const int nx = ns[s0];
+      pa[len++] = a;  // v[len-1] is dead: only v[0] was needed, and it has been read
+      s0 = nx;
     }
-    lengths[b] = (s0 == m.sink) ? len : -1;
-    for (int j = len; j < max_len; ++j) {
-      paths[(size_t)b * max_len + j] = pad;
-      if (path_arcs) path_arcs[(size_t)b * max_len + j] = -1;
-    }
+    res[0] = len;
+    res[1] = (s0 == m.sink) ? 1 : 0;
+  }
+  __syncthreads();
+  const int len = res[0];
+  if (tid == 0) lengths[b] = res[1] ? len : -1;
+  for (int j = tid; j < max_len; j += kVitThreads) {
+    const int a = j < len ? pa[j] : -1;
+    paths[(size_t)b * max_len + j] = a >= 0 ? lat.arc_label[a] : pad;
+    if (path_arcs) path_arcs[(size_t)b * max_len + j] = a;
   }
 }
 
@@ -1600,9 +1685,9 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (!best || !paths || !lengths || max_len <= 0) return NFST_ERR_ARG;
-  const int64_t lds = (int64_t)lat->max_rows * 8;
+  const int64_t lds = (int64_t)lat->max_rows * 12 + (int64_t)lat->vocab * 4 + 16;
   if ((rc = set_lds(k_viterbi, lds))) return rc;
-  hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(64), (size_t)lds, (hipStream_t)stream, *lat,
+  hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(kVitThreads), (size_t)lds, (hipStream_t)stream, *lat,
                      *scores, best, paths, path_arcs, lengths, (int)max_len, (int)pad);
   return hip_status(hipGetLastError());
 }

@@ -17,7 +17,8 @@
 __device__ unsigned long long g_dbg[8192];
 extern "C" int nfst_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long)*8192); }
 namespace {
-#define RT(slot) do { unsigned long long r_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); if ((threadIdx.x & 63) == 0) g_dbg[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = r_; } while (0)
+#define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define DUMP(a, b, c, d, e) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 7) { unsigned long long *o_ = g_dbg + (threadIdx.x >> 6) * 16; o_[0] = (a); o_[1] = (b); o_[2] = (c); o_[3] = (d); o_[4] = (e); } } while (0)
 
 constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -367,9 +368,12 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
   int issued = min(n_tiles, RS);  // loader_start issued these
   uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
   int freed = 0;                  // copy of the decoder's counter
-  int pub = 0;                    // tiles published in rland
+  int pub = 0;
+  unsigned long long l0, l1, lt0, lt1, lw_pub = 0, lw_vm = 0, lsleep = 0; TSTAMP(lt0);
   auto publish_oldest = [&]() {
+    TSTAMP(l0);
     wait_tiles_in_flight<OPS, AHEAD>(issued - pub - 1);
+    TSTAMP(l1); lw_pub += l1 - l0;
     ++pub;
     lds_flag_store(rland, pub);
   };
@@ -378,7 +382,7 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
       freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
       if (issued - freed >= RS) {
         if (pub < issued) publish_oldest();
-        else __builtin_amdgcn_s_sleep(1);
+        else { ++lsleep; __builtin_amdgcn_s_sleep(1); }
       }
       continue;
     }
@@ -386,12 +390,15 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
     ++issued;
     rb = (rb + RB == raw_end) ? raw_base : rb + RB;
     if (issued - pub > AHEAD) {
+      TSTAMP(l0);
       vm_wait<OPS * AHEAD>();
+      TSTAMP(l1); lw_vm += l1 - l0;
       pub = issued - AHEAD;
       lds_flag_store(rland, pub);
     }
   }
   while (pub < n_tiles) publish_oldest();
+  TSTAMP(lt1); DUMP(lt1 - lt0, lw_vm, lw_pub, n_tiles, lsleep);
 }
 
 // ---- decoder wave -----------------------------------------------------------------
@@ -472,6 +479,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
   int issue_next = AHEAD;                                   // SELF: that tile
   const int last = n_tiles - 1;
   int freed = 0, landed = 0;
+  unsigned long long d0, d1, dt0, dt1, dw_raw = 0, dw_prog = 0, dpolls = 0; TSTAMP(dt0);
   // makes sure the raw words of tile need-1 are in the staging ring (called once per tile, in order)
   auto wait_raw = [&](int need) {
     if (SELF) {
@@ -483,9 +491,13 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
       vm_wait<OPS * AHEAD>();
       return;
     }
-    while (__builtin_expect(landed < need, 0)) {
-      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(rland));
-      if (landed < need) __builtin_amdgcn_s_sleep(1);
+    if (landed < need) {
+      TSTAMP(d0);
+      while (landed < need) {
+        landed = __builtin_amdgcn_readfirstlane(lds_flag_load(rland));
+        if (landed < need) __builtin_amdgcn_s_sleep(1);
+      }
+      TSTAMP(d1); dw_raw += d1 - d0;
     }
     asm volatile("" ::: "memory");
   };
@@ -508,9 +520,14 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 #pragma unroll
     for (int j = 0; j < U; ++j) oa[j] = (cur.rc[j] & 0xffffu) + val_base;
     // --- the ring slot must be free: tile t - R consumed
-    while (__builtin_expect(t - freed >= R, 0)) {
-      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
-      if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
+    if (t - freed >= R) {
+      TSTAMP(d0);
+      while (t - freed >= R) {
+        freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
+        ++dpolls;
+        if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
+      }
+      TSTAMP(d1); dw_prog += d1 - d0;
     }
     asm volatile("" ::: "memory");
     *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
@@ -555,7 +572,8 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     if (t + 1 >= n_tiles) break;
     step(t + 1, rbb, tb, ra, ta);
   }
-  if (SELF) vm_wait<0>();  // nothing of the staging ring stays in flight
+  if (SELF) vm_wait<0>();
+  TSTAMP(dt1); DUMP(dt1 - dt0, dw_raw, dw_prog, n_tiles, dpolls);
 }
 
 // decoded tile in the sweep wave's registers
@@ -599,11 +617,17 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   if (n_tiles <= 0) return;
   constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;  // bytes per ring slot
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+  unsigned long long s0, s1, st0, st1, sw = 0, spolls = 0; TSTAMP(st0);
   int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
   auto wait_landed = [&](int need) {
-    while (__builtin_expect(landed < need, 0)) {
-      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
-      if (landed < need) __builtin_amdgcn_s_sleep(1);
+    if (landed < need) {
+      TSTAMP(s0);
+      while (landed < need) {
+        landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+        ++spolls;
+        if (landed < need) __builtin_amdgcn_s_sleep(1);
+      }
+      TSTAMP(s1); sw += s1 - s0;
     }
     asm volatile("" ::: "memory");
   };
@@ -680,6 +704,7 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
     if (T + 1 >= n_tiles) break;
     step(T + 1, db, cb, da, ca, true);
   }
+  TSTAMP(st1); DUMP(st1 - st0, sw, spolls, n_tiles, 0);
 }
 
 // role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder.
@@ -820,7 +845,6 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
-  RT(0);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
@@ -888,13 +912,11 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       }
     }
   }
-  RT(1);
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 4 / 5 load for them
   if (wv < (kSelf ? 4 : 6))
     run_sweep<EXTRA, kSelf, kAhead>(wv >> 1, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
                      bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex, lane);
-  RT(2);
   __syncthreads();
-  RT(3);
   const float2 zme = beta[0];
   if (tid == 0) {
     const double z = me_log64(zme);
@@ -968,8 +990,6 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       for (int l = tid; l < lat.vocab; l += NT) gout[l] = gth[l];
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  RT(4);
 }
 
 // ------------------------------------------------------------------ Viterbi
@@ -1523,30 +1543,28 @@ static int cu_count() {
   return n;
 }
 
-// Ring sizes per sweep from the LDS budget of one workgroup.  deep = the workgroup has a
-// CU's 160 KiB to itself (deep staging ring); otherwise two workgroups share it when the
-// lattices are small enough.  Returns R (decoded slots, kMinRing .. kMaxRing; 0 = does not
-// fit) and the staging slots in *rs.
-static int ring_slots(const LdsPlan &plan, bool fb, bool extra, bool deep, int *rs) {
+// Ring sizes per sweep from the LDS budget of one workgroup, and which kernel flavour runs.
+//   deep   (at most one lattice per CU): loader + decoder + sweep waves, deep staging ring;
+//   shared (more lattices than CUs): the decoder loads for itself, shallow staging ring, and
+//          two workgroups share a CU's 160 KiB when the lattices are small enough.
+// A lattice too large for the deep rings runs the shared flavour with the whole CU.
+struct RingCfg { int R, RS; bool self; };
+static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, RingCfg *c) {
   const int n_rings = fb ? 2 : 1;
   const int64_t slot = (int64_t)kSlotWords * 4 * n_rings;
   auto fixed = [&](int RS) { return fb ? plan.fb_bytes(0, RS, extra) : plan.bwd_bytes(0, RS, extra); };
+  auto clampr = [](int64_t r) { return (int)(r > kMaxRing ? kMaxRing : r); };
   if (deep) {
-    *rs = kRawSlotsDeep;
-    const int64_t r = (kMaxLds - fixed(*rs)) / slot;
-    if (r >= kMinRing) return (int)(r > kMaxRing ? kMaxRing : r);
-    // a very large lattice: shallow staging ring, whatever is left for the decoded ring
+    const int64_t r = (kMaxLds - fixed(kRawSlotsDeep)) / slot;
+    if (r >= kMinRing) { *c = {clampr(r), kRawSlotsDeep, false}; return true; }
   } else {
-    *rs = kRawSlotsShared;
-    const int64_t r = (kMaxLds / 2 - fixed(*rs)) / slot;
-    if (r >= kMinRing + 1) return (int)(r > kMaxRing ? kMaxRing : r);
+    const int64_t r = (kMaxLds / 2 - fixed(kRawSlotsShared)) / slot;
+    if (r >= kMinRing + 1) { *c = {clampr(r), kRawSlotsShared, true}; return true; }
   }
-  // (deep kernels run with a ring of kRawSlotsShared slots too: the loader then simply waits for
-  // the decoder earlier)
-  *rs = deep ? kDmaAheadDeep + 2 : kRawSlotsShared;
-  const int64_t r = (kMaxLds - fixed(*rs)) / slot;
-  if (r < kMinRing) return 0;
-  return (int)(r > kMaxRing ? kMaxRing : r);
+  const int64_t r = (kMaxLds - fixed(kRawSlotsShared)) / slot;
+  if (r < kMinRing) return false;
+  *c = {clampr(r), kRawSlotsShared, true};
+  return true;
 }
 
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta, double *logz64,
@@ -1556,10 +1574,9 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   if ((rc = check_scores(lat, scores))) return rc;
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
-  const bool deep = lat->n_lattices <= cu_count();
-  int RS = 0;
-  const int R = ring_slots(plan, false, extra, deep, &RS);
-  if (R == 0) return NFST_ERR_LIMIT;
+  RingCfg cfg;
+  if (!ring_config(plan, false, extra, lat->n_lattices <= cu_count(), &cfg)) return NFST_ERR_LIMIT;
+  const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.bwd_bytes(R, RS, extra);
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
   {                                                                                                    \
@@ -1567,7 +1584,8 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
     hipLaunchKernelGGL((k_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,             \
                        (hipStream_t)stream, *lat, *scores, R, RS, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
-  if (deep) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
+  // 512 threads: loader + decoder + sweep (deep); 256 threads: self-loading decoder + sweep
+  if (!cfg.self) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
   else { if (extra) NFST_LAUNCH_BWD(256, true) else NFST_LAUNCH_BWD(256, false) }
 #undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
@@ -1584,10 +1602,9 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
   const int cus = cu_count();
-  const bool deep = lat->n_lattices <= cus;
-  int RS = 0;
-  const int R = ring_slots(plan, true, extra, deep, &RS);
-  if (R == 0) return NFST_ERR_LIMIT;
+  RingCfg cfg;
+  if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
+  const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
@@ -1596,7 +1613,9 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
                        (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, posterior, \
                        grad_theta, (float2 *)beta_me);                                                  \
   }
-  if (deep) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
+  // 1024 threads: loaders + decoders + sweeps and 10 more waves for the posterior pass (deep);
+  // 512 / 256 threads: self-loading decoders + sweeps, two workgroups per CU when they fit
+  if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
   else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
   else { if (extra) NFST_LAUNCH_FB(256, true) else NFST_LAUNCH_FB(256, false) }
 #undef NFST_LAUNCH_FB
