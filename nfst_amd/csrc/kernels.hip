@@ -1156,62 +1156,121 @@ __device__ __forceinline__ float arc_score(const float *theta, const float *arc_
   return s;
 }
 
-__global__ __launch_bounds__(64) void k_sample(nfst_batch lat, nfst_scores sc,
-                                               const float2 *beta_me, const double *logz64, int K,
-                                               int max_len, const float *uniforms, uint64_t seed,
-                                               int pad, int32_t *paths, int32_t *path_arcs,
-                                               int32_t *lengths, float *logq, int32_t *status) {
-  const int b = blockIdx.x;
-  const int k = blockIdx.y * 64 + threadIdx.x;
-  if (k >= K) return;
+// One walk per 16-lane row (a DPP "row"): the arcs of the current state are spread over the
+// row's lanes, 16 at a time; probabilities p = w * beta[dst] / beta[state] come from the
+// lattice's beta values staged in LDS, the CDF is an inclusive scan inside the row
+// (row_shr 1, 2, 4, 8 with zero fill) and the first lane with u < cdf wins (arcs with p = 0
+// never do).  A block is 16 walks of one lattice.
+constexpr int kSampleThreads = 256, kWalksPerBlock = kSampleThreads / 16;
+template <int SHIFT>
+__device__ __forceinline__ float row_shr_zero(float v) {  // lane i gets lane i-SHIFT of its row, 0 if there is none
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SHIFT, 0xf, 0xf, true));
+}
+__global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_scores sc,
+                                                           const float2 *beta_me, const double *logz64, int K,
+                                                           int max_len, const float *uniforms, uint64_t seed,
+                                                           int pad, int stage_theta, int32_t *paths, int32_t *path_arcs,
+                                                           int32_t *lengths, float *logq, int32_t *status) {
+  extern __shared__ float2 lds[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r = tid & 15;                                // lane within the row
+  const int k = blockIdx.y * kWalksPerBlock + (tid >> 4);  // this row's walk
   const Meta m = load_meta(lat.meta, b);
   const float *theta = sc.theta + (size_t)sc.theta_stride * b;
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
   const int32_t *rp = lat.row_ptr + m.row_off + b;
-  const float2 *bme = beta_me + m.row_off;
-  const size_t walk = (size_t)b * K + k;
+  float2 *bl = lds;                                      // beta (m, e) of the lattice's rows
+  float *tls = (float *)(bl + lat.max_rows);             // label scores (staged unless the vocabulary is huge)
+  for (int i = tid; i < m.n_rows; i += kSampleThreads) bl[i] = beta_me[m.row_off + i];
+  if (stage_theta) for (int i = tid; i < lat.vocab; i += kSampleThreads) tls[i] = theta[i];
+  __syncthreads();
+  const float *tl = stage_theta ? (const float *)tls : theta;
+  const bool live = k < K;
+  const size_t walk = (size_t)b * K + (live ? k : 0);
   int32_t *out = paths + walk * max_len;
   int32_t *outa = path_arcs ? path_arcs + walk * max_len : nullptr;
   int s = 0, t = 0;
   float tot = 0.0f;
   bool ok = true;
-  while (s != m.sink) {
-    if (t >= max_len) { ok = false; break; }
-    const float u = uniforms ? uniforms[walk * max_len + t] : philox_uniform(seed, (uint32_t)walk, (uint32_t)t);
-    const float2 bs = bme[s];
+  bool active = live;
+  while (true) {
+    if (active && s == m.sink) active = false;
+    if (active && t >= max_len) { ok = false; active = false; }
+    if (!__any(active)) break;
+    float u = 0.0f;
+    float2 bs = make_float2(1.0f, 0.0f);
+    int a0 = 0, a1 = 0;
+    if (active) {
+      u = uniforms ? uniforms[walk * max_len + t] : philox_uniform(seed, (uint32_t)walk, (uint32_t)t);
+      bs = bl[s];
+      a0 = rp[s];
+      a1 = rp[s + 1];
+    }
     const float rs = 1.0f / bs.x;
     const int es = __float_as_int(bs.y);
-    float cum = 0.0f, sc_ch = 0.0f, sc_last = 0.0f;
-    int chosen = -1, last = -1;
-    for (int a = rp[s]; a < rp[s + 1]; ++a) {
-      const int d = lat.arc_dst[a];
-      if (d == s) continue;
-      const float x = arc_score(theta, arc_w, sc.arc_scores, lat.arc_label[a], a);
-      const ME wgt = exp_split(x);
-      const float2 bd = bme[d];
-      const float p = ldexpf((wgt.m * bd.x) * rs, max(wgt.e + __float_as_int(bd.y) - es, -300));
-      if (p > 0.0f) {
-        cum += p;
-        last = a;
-        sc_last = x;
-        if (u < cum) { chosen = a; sc_ch = x; break; }
+    float cum_base = 0.0f, sc_ch = 0.0f, sc_last = 0.0f;
+    int chosen = -1, last = -1, d_ch = 0, d_last = 0;
+    bool more = active;
+    for (int c = a0; __any(more); c += 16) {
+      more = more && c < a1 && chosen < 0;
+      const int a = c + r;
+      float p = 0.0f, x = 0.0f;
+      int d = 0;
+      if (more && a < a1) {
+        const uint32_t sd = lat.arc_sd[a];
+        d = (int)(sd >> 16);
+        if (d != s) {
+          x = tl[lat.arc_l16[a]];
+          if (arc_w) x += arc_w[a];
+          if (sc.arc_scores) x += sc.arc_scores[a];
+          const ME wgt = exp_split(x);
+          const float2 bd = bl[d];
+          p = ldexpf((wgt.m * bd.x) * rs, max(wgt.e + __float_as_int(bd.y) - es, -300));
+        }
+      }
+      float v = p;
+      v += row_shr_zero<1>(v);
+      v += row_shr_zero<2>(v);
+      v += row_shr_zero<4>(v);
+      v += row_shr_zero<8>(v);
+      const float cum = cum_base + v;
+      const int sh = (int)(threadIdx.x & 48);  // first lane of this row within the wave
+      const uint32_t hit = (uint32_t)(__ballot(more && p > 0.0f && u < cum) >> sh) & 0xffffu;
+      const uint32_t pos = (uint32_t)(__ballot(more && p > 0.0f) >> sh) & 0xffffu;
+      const int f = hit ? __builtin_ctz(hit) : 0, l = pos ? 31 - __builtin_clz(pos) : 0;
+      const float x_f = __shfl(x, f, 16), x_l = __shfl(x, l, 16), c_end = __shfl(cum, 15, 16);
+      const int d_f = __shfl(d, f, 16), d_l = __shfl(d, l, 16);
+      if (more) {
+        if (hit) { chosen = c + f; sc_ch = x_f; d_ch = d_f; }
+        else {
+          cum_base = c_end;
+          if (pos) { last = c + l; sc_last = x_l; d_last = d_l; }
+        }
       }
     }
-    if (chosen < 0) { chosen = last; sc_ch = sc_last; }
-    if (chosen < 0) { ok = false; break; }
-    out[t] = lat.arc_label[chosen];
-    if (outa) outa[t] = chosen;
-    tot += sc_ch;
-    s = lat.arc_dst[chosen];
-    ++t;
+    if (active) {
+      if (chosen < 0) { chosen = last; sc_ch = sc_last; d_ch = d_last; }
+      if (chosen < 0) { ok = false; active = false; }
+      else {
+        if (r == 0) {
+          out[t] = lat.arc_l16[chosen];
+          if (outa) outa[t] = chosen;
+        }
+        tot += sc_ch;
+        s = d_ch;
+        ++t;
+      }
+    }
   }
-  if (!ok) atomicExch(status, NFST_ERR_LENGTH);
-  lengths[walk] = ok ? t : -1;
-  for (int j = t; j < max_len; ++j) { out[j] = pad; if (outa) outa[j] = -1; }
-  logq[walk] = ok ? (float)((double)tot - logz64[b]) : kNegInf;
+  if (!live) return;
+  if (!ok && r == 0) atomicExch(status, NFST_ERR_LENGTH);
+  if (r == 0) {
+    lengths[walk] = ok ? t : -1;
+    logq[walk] = ok ? (float)((double)tot - logz64[b]) : kNegInf;
+  }
+  for (int j = t + r; j < max_len; j += 16) { out[j] = pad; if (outa) outa[j] = -1; }
 }
 
-// binary search of `label` in the canonical row [r0, r1); returns arc id or -1
 __device__ __forceinline__ int find_arc(const int32_t *arc_label, int r0, int r1, int label) {
   int lo = r0, hi = r1;
   while (lo < hi) {
@@ -1701,9 +1760,14 @@ int nfst_sample_paths(const nfst_batch *lat, const nfst_scores *scores, const fl
   if ((rc = check_scores(lat, scores))) return rc;
   if (!beta_me || !logz64 || !paths || !lengths || !logq || !status || k <= 0 || max_len <= 0)
     return NFST_ERR_ARG;
-  hipLaunchKernelGGL(k_sample, dim3(lat->n_lattices, (k + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+  if (!lat->arc_sd || !lat->arc_l16) return NFST_ERR_ARG;
+  const int stage_theta = (int64_t)lat->max_rows * 8 + (int64_t)lat->vocab * 4 <= 96 * 1024;
+  const int64_t lds = (int64_t)lat->max_rows * 8 + (stage_theta ? (int64_t)lat->vocab * 4 : 0);
+  if ((rc = set_lds(k_sample, lds))) return rc;
+  hipLaunchKernelGGL(k_sample, dim3(lat->n_lattices, (k + kWalksPerBlock - 1) / kWalksPerBlock), dim3(kSampleThreads),
+                     (size_t)lds, (hipStream_t)stream,
                      *lat, *scores, (const float2 *)beta_me, logz64, (int)k, (int)max_len, uniforms,
-                     seed, (int)pad, paths, path_arcs, lengths, logq, status);
+                     seed, (int)pad, stage_theta, paths, path_arcs, lengths, logq, status);
   return hip_status(hipGetLastError());
 }
 
