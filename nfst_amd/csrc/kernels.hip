@@ -1421,10 +1421,26 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t *mk = marks + n * T;
   const float rtemp = 1.0f / temp;
+  // Row-level legality (scorers.py:59-83) only depends on three row flags; which of this lane's
+  // 4 NV columns are illegal under each is a lane constant, one bit per column:
+  //   normal / first row: bos, pad;  after eos or pad: everything but pad;  forced end: everything but eos
+  uint32_t m_norm = 0, m_end = 0, m_force = 0;
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = (c * 64 + lane) * 4 + k;
+      const uint32_t bit = 1u << (c * 4 + k);
+      const bool oob = col >= V;
+      if (oob || col == bos || col == pad) m_norm |= bit;
+      if (oob || col == bos || col != pad) m_end |= bit;
+      if (oob || col == bos || col == pad || col != eos) m_force |= bit;
+    }
   float acc = 0.0f;
   for (int t0 = wave * RB; t0 < T; t0 += 4 * RB) {
     float4 v[RB][NV];
     int lab[RB], prev[RB];
+    float lraw[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int t = min(t0 + r, T - 1);  // clamped: rows past the end are loaded but not used
@@ -1438,31 +1454,30 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
       prev[r] = t > 0 ? (int)mk[t - 1] : -1;
     }
 #pragma unroll
+    for (int r = 0; r < RB; ++r)  // the realised marks' scores: all RB gathers in flight together (L2 hits)
+      lraw[r] = scores[((size_t)n * T + min(t0 + r, T - 1)) * V + lab[r]];
+#pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int t = t0 + r;
       if (t >= T) break;
       float sel;
       const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
-      const float lraw = scores[((size_t)n * T + t) * V + lab[r]];  // L1/L2 hit: the row was just read
-      const float lx = ((lab[r] == pad ? 0.0f : lraw) + lmsk) / temp + lmsk;
+      const float lx = ((lab[r] == pad ? 0.0f : lraw[r]) + lmsk) / temp + lmsk;
       sel = lx;
       if (normalize || smoothing > 0.0f) {
-        // row-level legality (scorers.py:59-83): hoisted out of the per-column loop
         const bool first = t == 0;
         const bool ended = !first && (prev[r] == eos || prev[r] == pad);
         const bool force = !first && max_length >= 0 && t > max_length && !ended;
+        const uint32_t bad = ended ? m_end : (force ? m_force : m_norm);
         float mx = kNegInf;
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
           float *e = reinterpret_cast<float *>(&v[r][c]);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int col = (c * 64 + lane) * 4 + k;
-            bool bad = col == bos;
-            bad |= first ? (col == pad) : (ended ? (col != pad) : (col == pad));
-            bad |= force && col != eos;
-            const float x = (col == pad ? 0.0f : e[k]) * rtemp;
-            e[k] = (bad || col >= V) ? kNegInf : x;
+            // the pad column counts as score 0 (scorers.py:1679-1683); it is only legal in `ended` rows
+            const float x = ended ? 0.0f : e[k] * rtemp;
+            e[k] = (bad & (1u << (c * 4 + k))) ? kNegInf : x;
             mx = fmaxf(mx, e[k]);
           }
         }
