@@ -105,7 +105,7 @@ extern "C" {
 typedef struct nfst_batch {
   int32_t n_lattices;
   int32_t vocab;
-  int32_t max_rows;        /* max n_rows over the batch */
+  int32_t max_rows;        /* max over the batch of the LDS rows a lattice needs: n_rows + scratch rows of its tile programs */
   int32_t max_tiles;       /* max tiles of one program over the batch */
   int32_t weighted;        /* arc_w holds the table's float weights */
   int32_t reserved0;

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
   float *tl = (float *)(ns + lat.max_rows);  // [V] label scores
   int *progress = (int *)(tl + lat.vocab);
   const float *tg = sc.theta + (size_t)sc.theta_stride * b;
-  for (int i = tid; i < m.n_rows; i += kVitThreads) { v[i] = kNegInf; bp[i] = -1; }
+  for (int i = tid; i < lat.max_rows; i += kVitThreads) { v[i] = kNegInf; bp[i] = -1; }  // incl. scratch rows
   for (int i = tid; i < lat.vocab; i += kVitThreads) tl[i] = tg[i];
   if (tid == 0) *progress = 0;
   __syncthreads();
@@ -1065,6 +1065,9 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
     for (int j = 0; j < 4; ++j) {
       const int other = (int)((rcs[j] & 0xffffu) >> 3);
       if (cas[j] >= 0) vit_take(bv, ba, bn, tl[rcs[j] >> 16] + xs[j] + v[other], cas[j], other);
+      // a unit-label record stands for what row `other` holds -- the state's own earlier pieces
+      // (carry) or a scratch row of a partial group: its best arc competes as such
+      else if (j < U && (int)(rcs[j] >> 16) == lat.vocab + 1 && bp[other] >= 0) vit_take(bv, ba, bn, v[other], bp[other], ns[other]);
     }
     const int gl = (int)((ctl >> 20) & 7u);
     const int gmax = (int)((__builtin_amdgcn_readfirstlane(ctl) >> 23) & 7u);
@@ -1089,7 +1092,6 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
 #undef NFST_SHFL32
     if (ctl & (1u << 31)) {
       const uint32_t sid = (ctl & 0xffffu) >> 3;
-      if ((ctl & (1u << 30)) && bp[sid] >= 0) vit_take(bv, ba, bn, v[sid], bp[sid], ns[sid]);
       v[sid] = bv;
       bp[sid] = (ba == kNone) ? -1 : ba;
       ns[sid] = bn;

@@ -35,7 +35,7 @@ struct Lat {
   std::vector<int32_t> row_ptr;  // n_rows + 1, relative
   std::vector<uint32_t> fwd, bwd;
   std::vector<int32_t> fwd_perm, bwd_perm;  // per tile slot: relative canonical arc id or -1
-  int fwd_tiles = 0, bwd_tiles = 0, fwd_u = 4, bwd_u = 4, fwd_wide = 0, bwd_wide = 0, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
+  int fwd_tiles = 0, bwd_tiles = 0, fwd_u = 4, bwd_u = 4, fwd_wide = 0, bwd_wide = 0, scratch_rows = 0, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
   int err = NFST_OK;
 };
 
@@ -54,32 +54,55 @@ inline int ceil_log2(int x) { int g = 0; while ((1 << g) < x) ++g; return g; }
 // leader lane also carries the "accumulate" flag (the max-plus kernel keeps the earlier
 // back pointer when the carry wins).  max_g = 3 ("narrow": groups of up to 8 lanes, the
 // sweep needs no cross-row reduction stage) or 6 ("wide": up to the whole wave).
-struct Piece { int32_t state; int32_t begin, end; bool accum; };  // arcs [begin,end) of the state's list
+// A state with many more arcs than a group holds (three or more groups' worth) is summed as
+// a tree instead of a chain: its arcs are spread over PARTIAL groups that write scratch rows
+// (ids from n_rows up, reused from level to level) -- up to eight of them side by side in one
+// tile -- and a COMBINE piece in a later tile adds the scratch rows up with unit-label records.
+struct Piece {
+  int32_t state;       // row that receives the sum (a scratch row for a partial group)
+  int32_t begin, end;  // arcs [begin,end) of the state's list, or scratch rows [begin,end) for a combine piece
+  bool accum;          // continuation piece: starts with the carry record
+  bool units;          // combine piece: its records are unit-label records of scratch rows
+};
 
-struct TileCount { int tiles = 0, wide = 0; };  // wide: tiles whose largest group exceeds 8 lanes
+struct TileCount { int tiles = 0, wide = 0, scratch = 0; };  // wide: tiles whose largest group exceeds 8 lanes
 
 template <class ArcsOf, class Other>
-void emit_level(const std::vector<int32_t> &states, int U, int max_g, uint32_t null_label, ArcsOf arcs_of, Other other,
-                const std::vector<int32_t> &list, const std::vector<int32_t> &label,
+void emit_level(const std::vector<int32_t> &states, int U, int max_g, uint32_t null_label, int n_rows, ArcsOf arcs_of,
+                Other other, const std::vector<int32_t> &list, const std::vector<int32_t> &label,
                 std::vector<uint32_t> *stream, std::vector<int32_t> *perm, TileCount &count) {
   const int cap = (1 << max_g) * U;
   const uint32_t null_rec = null_label << 16, unit_label = null_label + 1;
   // pass k holds the k-th piece of every state of the level
   std::vector<std::vector<Piece>> passes(1);
+  auto add = [&](size_t k, const Piece &p) {
+    if (passes.size() <= k) passes.emplace_back();
+    passes[k].push_back(p);
+  };
+  // a chain of pieces over the index range [b, e): the first takes `cap` slots, every
+  // continuation piece one less (its carry), starting in pass k0
+  auto chain = [&](int32_t state, int b, int e, bool units, size_t k0) {
+    for (size_t k = k0;; ++k) {
+      const int room = (k == k0) ? cap : cap - 1;
+      const int stop = std::min(e, b + room);
+      add(k, {state, b, stop, k > k0, units});
+      b = stop;
+      if (b >= e) break;
+    }
+  };
+  int scratch = n_rows;  // next free scratch row of this level
   for (int32_t s : states) {
     auto r = arcs_of(s);
-    int b = r.first;
-    size_t k = 0;
-    for (;;) {
-      const int room = (k == 0) ? cap : cap - 1;  // a continuation piece spends one slot on the carry
-      const int e = std::min(r.second, b + room);
-      if (passes.size() <= k) passes.emplace_back();
-      passes[k].push_back({s, b, e, k > 0});
-      b = e;
-      ++k;
-      if (b >= r.second) break;
+    const int d = r.second - r.first;
+    if (max_g == 3 && d > 2 * cap && n_rows + (d + cap - 1) / cap + (scratch - n_rows) <= NFST_MAX_ROWS) {
+      const int first = scratch;
+      for (int b = r.first; b < r.second; b += cap) add(0, {scratch++, b, std::min(r.second, b + cap), false, false});
+      chain(s, first, scratch, true, 1);
+    } else {
+      chain(s, r.first, r.second, false, 0);
     }
   }
+  count.scratch = std::max(count.scratch, scratch - n_rows);
   auto lanes_of = [&](const Piece &p) { return std::max(1, (p.end - p.begin + (p.accum ? 1 : 0) + U - 1) / U); };
   for (auto &pieces : passes) {
     std::stable_sort(pieces.begin(), pieces.end(), [&](const Piece &a, const Piece &b) {
@@ -113,6 +136,8 @@ void emit_level(const std::vector<int32_t> &states, int U, int max_g, uint32_t n
               const size_t at = (size_t)(lane + r) * U + j;
               if (p.accum && slot == 0) {
                 rec[at] = ((uint32_t)p.state << 3) | (unit_label << 16);
+              } else if (p.units) {
+                rec[at] = ((uint32_t)(p.begin + slot - (p.accum ? 1 : 0)) << 3) | (unit_label << 16);
               } else {
                 const int32_t arc = list[p.begin + slot - (p.accum ? 1 : 0)];
                 rec[at] = ((uint32_t)other(arc) << 3) | ((uint32_t)label[arc] << 16);
@@ -216,8 +241,8 @@ void schedule(Lat &L, int vocab, const Opts &o) {
         if ((o.group_mode == 1 && wide) || (o.group_mode == 2 && !wide)) continue;
         TileCount c;
         for (int t = 1; t <= D; ++t) {
-          if (backward) emit_level(by_height[t], us[q], wide ? 6 : 3, null_label, out_of, dst_of, out_list, L.label, nullptr, nullptr, c);
-          else emit_level(by_depth[t], us[q], wide ? 6 : 3, null_label, in_of, src_of, in_list, L.label, nullptr, nullptr, c);
+          if (backward) emit_level(by_height[t], us[q], wide ? 6 : 3, null_label, n, out_of, dst_of, out_list, L.label, nullptr, nullptr, c);
+          else emit_level(by_depth[t], us[q], wide ? 6 : 3, null_label, n, in_of, src_of, in_list, L.label, nullptr, nullptr, c);
         }
         if (wide && c.wide == 0 && o.group_mode != 2) continue;  // same program as the narrow one
         const double cost = (double)c.tiles * (330.0 + 55.0 * us[q] + (wide ? 60.0 : 0.0)) + 450.0 * c.wide;
@@ -230,11 +255,12 @@ void schedule(Lat &L, int vocab, const Opts &o) {
   L.fwd.clear(); L.bwd.clear(); L.fwd_perm.clear(); L.bwd_perm.clear();
   TileCount cb, cf;
   for (int t = 1; t <= D; ++t) {
-    emit_level(by_height[t], L.bwd_u, L.bwd_wide ? 6 : 3, null_label, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, cb);
-    emit_level(by_depth[t], L.fwd_u, L.fwd_wide ? 6 : 3, null_label, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, cf);
+    emit_level(by_height[t], L.bwd_u, L.bwd_wide ? 6 : 3, null_label, n, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, cb);
+    emit_level(by_depth[t], L.fwd_u, L.fwd_wide ? 6 : 3, null_label, n, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, cf);
   }
   L.bwd_tiles = cb.tiles;
   L.fwd_tiles = cf.tiles;
+  L.scratch_rows = std::max(cb.scratch, cf.scratch);
 }
 
 template <class F>
@@ -296,7 +322,7 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
     // 256-byte boundary (LDS-DMA chunks are 16 B per lane)
     fw += (int64_t)L.fwd.size(); bw += (int64_t)L.bwd.size();
     fs += (int64_t)L.fwd_perm.size(); bs += (int64_t)L.bwd_perm.size();
-    max_rows = std::max(max_rows, L.n_rows);
+    max_rows = std::max(max_rows, L.n_rows + L.scratch_rows);
     max_tiles = std::max(max_tiles, std::max(L.fwd_tiles, L.bwd_tiles));
     if (arcs > 0x7fffff00ll || fw > 0x7ffff000ll || bw > 0x7ffff000ll || rows > 0x7fffff00ll ||
         fs > 0x7fffff00ll || bs > 0x7fffff00ll) {

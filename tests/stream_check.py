@@ -25,11 +25,13 @@ def replay(lat, b, direction, theta, extra=None):
     assert U in (1, 2, 4) and off % 64 == 0
     ST = 64 * (1 + U)
     src = lat.arc_src.cpu().numpy(); dst = lat.arc_dst.cpu().numpy(); lab = lat.arc_label.cpu().numpy()
-    val = np.full(n_rows, -np.inf)
-    done = np.zeros(n_rows, bool)
+    n_lds = max(n_rows, int(lat.max_rows))  # + scratch rows of partial groups
+    val = np.full(n_lds, -np.inf)
+    done = np.zeros(n_lds, bool)
     val[start] = 0.0
     done[start] = True
     seen = []
+    owner = {}  # scratch row -> the state whose arcs its partial group sums
     for T in range(tiles):
         base = off + T * ST
         ctl = s[base: base + 64]
@@ -58,20 +60,25 @@ def replay(lat, b, direction, theta, extra=None):
                     assert int(rec[lane + r, j]) & 7 == 0
                     other, l = (int(rec[lane + r, j]) & 0xFFFF) >> 3, int(rec[lane + r, j]) >> 16
                     if ca < 0:
-                        if l == V + 1:  # carry record of a continuation piece: weight one, operand = the state
-                            assert r == 0 and j == 0 and other == sid and (c >> 30) & 1
+                        if l == V + 1 and other == sid:  # carry record of a continuation piece: weight one
+                            assert r == 0 and j == 0 and (c >> 30) & 1
                             assert done[sid], "continuation piece before the state's first piece"
                             terms.append(val[sid])
                             carries += 1
+                        elif l == V + 1:  # combine piece: the sum a partial group left in a scratch row
+                            assert other >= n_rows and done[other] and sid < n_rows and owner.pop(other) == sid
+                            terms.append(val[other])
                         else:
                             assert l == V  # the null label
                         continue
                     assert leader or r > 0 or True
                     assert lab[ca] == l
-                    if direction == "fwd":
-                        assert src[ca] == other and dst[ca] == sid
-                    else:
-                        assert dst[ca] == other and src[ca] == sid
+                    mine = int(dst[ca] if direction == "fwd" else src[ca])
+                    assert int(src[ca] if direction == "fwd" else dst[ca]) == other
+                    if sid < n_rows:
+                        assert mine == sid
+                    else:  # partial group: all its arcs belong to one state, remembered for the combine piece
+                        assert owner.setdefault(sid, mine) == mine
                     assert done[other], "operand state not finished by an earlier tile"
                     x = float(theta[l]) + (float(extra[ca]) if extra is not None else 0.0)
                     terms.append(x + val[other])
@@ -90,4 +97,4 @@ def replay(lat, b, direction, theta, extra=None):
             done[sid] = True
     n_dp = int(m[_lib.META_N_DP])
     assert len(seen) == n_dp and len(set(seen)) == n_dp  # every DP arc exactly once
-    return val
+    return val[:n_rows]

@@ -200,7 +200,8 @@ def test_huge_degree_and_deep_lattices(dev):
     star = synth._finish(204, V, src, lab, dst)
     deep = synth.layered_lattice(5, n_states=1500, avg_degree=10.0, vocab=V, width=1, span=8)
     theta = synth.label_scores(2, V)
-    for opts in (dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4)):
+    for opts in (dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4), dict(group_mode=1),
+                 dict(group_mode=1, slots_per_lane=1), dict(group_mode=2)):
         lat = LatticeBatch.from_synth([star, deep], device=dev, **opts)
         r = ops.forward_backward(lat, torch.from_numpy(theta))
         for b, l in enumerate([star, deep]):
@@ -240,6 +241,22 @@ def test_viterbi_bit_exact(dev):
         assert np.array_equal(r.paths.cpu().numpy()[b, :n], path)
         assert np.array_equal(r.arcs.cpu().numpy()[b, :n] - int(lat.arc_off[b]), arcs)
         assert np.all(r.paths.cpu().numpy()[b, n:] == PAD)
+    # a state with 200 out-arcs: continuation pieces (wide groups) and partial groups + combine piece
+    # (narrow groups) must hand the best arc through their unit-label records
+    V = 256
+    src = [0] + [1] * 200 + list(range(2, 202)) + [202]
+    lab = [BOS] + list(range(3, 203)) + [5] * 200 + [EOS]
+    dst = [1] + list(range(2, 202)) + [202] * 200 + [203]
+    star = synth._finish(204, V, src, lab, dst)
+    theta = synth.label_scores(4, V)
+    best, path, arcs = O.viterbi(star.n_rows, star.src, star.label, star.dst, theta[star.label], 4000)
+    for opts in (dict(group_mode=1), dict(group_mode=2), dict(group_mode=1, slots_per_lane=1), dict(group_mode=2, slots_per_lane=1)):
+        lat = LatticeBatch.from_synth([star], device=dev, **opts)
+        r = ops.viterbi(lat, torch.from_numpy(theta), pad=PAD)
+        n = int(r.lengths[0])
+        assert n == len(path) and np.float32(best) == r.best.cpu().numpy()[0]
+        assert np.array_equal(r.paths.cpu().numpy()[0, :n], path)
+        assert np.array_equal(r.arcs.cpu().numpy()[0, :n], arcs)
 
 
 def test_posterior_sampling(dev):
