@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--slots", type=int, default=0, help="arc slots per lane of a tile (0 = packer's choice)")
+    ap.add_argument("--no-compact", action="store_true", help="32-bit arc records instead of the compact tile format")
     ap.add_argument("--group-mode", type=int, default=0, help="0 = packer's choice, 1 = narrow groups, 2 = wide groups")
     ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
     ap.add_argument("--graph", action="store_true", help="replay a HIP graph of the step instead of launching from Python "
@@ -138,7 +139,7 @@ def main():
     lats = synth.bench_batch(B, first_seed=1234 + rank * B, width=args.width)
     theta_np = synth.label_scores(1, 256)
     t0 = time.perf_counter()
-    lat = LatticeBatch.from_synth(lats, slots_per_lane=args.slots, group_mode=args.group_mode)
+    lat = LatticeBatch.from_synth(lats, slots_per_lane=args.slots, group_mode=args.group_mode, no_compact=args.no_compact)
     pack_s = time.perf_counter() - t0
     lat = lat.to(dev)
     theta = torch.from_numpy(theta_np).to(dev)

@@ -144,7 +144,7 @@ typedef struct nfst_pack_opts {
   int32_t slots_per_lane;  /* arc slots per lane of a tile: 1, 2 or 4 (0 = per lattice and direction, cheapest) */
   int32_t group_mode;      /* largest lane group of a state: 1 = narrow (8 lanes, more tiles for high-degree
                               states), 2 = wide (64 lanes), 0 = per lattice and direction, cheapest */
-  int32_t reserved1;
+  int32_t reserved1;       /* 1 = never use the compact (24-bit record) tile format (testing) */
 } nfst_pack_opts;
 
 /*

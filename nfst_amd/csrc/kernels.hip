@@ -80,7 +80,8 @@ __device__ __forceinline__ Meta load_meta(const int32_t *meta, int b) {
   r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_tiles = m[NFST_META_BWD_TILES];
   r.sink = m[NFST_META_SINK]; r.n_reach = m[NFST_META_N_REACH]; r.depth = m[NFST_META_DEPTH];
   r.n_dp = m[NFST_META_N_DP];
-  // slots per lane, and bit 8: the program has tiles with groups wider than 8 lanes
+  // program format code (1, 2, 4: slots per lane; 8: compact tiles), and bit 8: the program has
+  // tiles with groups wider than 8 lanes
   r.fwd_u = m[NFST_META_FWD_U] & 0xff; r.bwd_u = m[NFST_META_BWD_U] & 0xff;
   r.fwd_wide = (m[NFST_META_FWD_U] >> 8) & 1; r.bwd_wide = (m[NFST_META_BWD_U] >> 8) & 1;
   r.fwd_slot_off = m[NFST_META_FWD_SLOT_OFF]; r.bwd_slot_off = m[NFST_META_BWD_SLOT_OFF];
@@ -139,6 +140,11 @@ constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSl
 constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
 constexpr int kRawWordsX = kRawWords + 64 * 4;  // + the slots' canonical arc ids (kernels with per-arc extras)
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
+// program format code (meta word, bits 0..7): 1, 2, 4 = slots per lane with 32-bit records and a
+// separate control block; 8 = the compact tile: four slots per lane, 16 bytes per lane = control
+// word + four 24-bit records (state 13 bits | label 11 bits)
+__host__ __device__ constexpr int fmt_u(int F) { return F == 8 ? 4 : F; }
+__host__ __device__ constexpr int fmt_words(int F) { return F == 8 ? 256 : 64 * (1 + F); }
 constexpr int kMaxRing = 8, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
 
 template <int CTRL>
@@ -300,14 +306,23 @@ __device__ __forceinline__ void vm_wait() {  // at most N vector-memory operatio
 }
 
 // LDS-DMA instructions per tile
-template <int U, bool EXTRA>
-struct DmaOps { static constexpr int value = (U == 2 ? 3 : 2) + (EXTRA ? (U == 2 ? 2 : 1) : 0); };
+template <int F, bool EXTRA>
+struct DmaOps {
+  static constexpr int value = F == 8 ? (EXTRA ? 2 : 1) : (F == 2 ? 3 : 2) + (EXTRA ? (F == 2 ? 2 : 1) : 0);
+};
 
-// raw staging slot: [64 control words][64 U records]([64 U canonical arc ids])
-template <int U, bool EXTRA>
+// raw staging slot: [64 control words][64 U records]([64 U canonical arc ids]); compact tiles:
+// [64 x (control word, 3 record words)]([256 canonical arc ids])
+template <int F, bool EXTRA>
 __device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *perm, int tile, uint32_t slot_addr, int lane) {
-  const uint32_t *src = g + (size_t)tile * (64 * (1 + U));
+  constexpr int U = fmt_u(F);
+  const uint32_t *src = g + (size_t)tile * fmt_words(F);
   const int32_t *q = perm + (size_t)tile * (64 * U);
+  if (F == 8) {
+    lds_dma16(src + lane * 4, slot_addr);
+    if (EXTRA) lds_dma16(q + lane * 4, slot_addr + 1024);
+    return;
+  }
   lds_dma4(src + lane, slot_addr);
   if (U == 4) {
     lds_dma16(src + 64 + lane * 4, slot_addr + 256);
@@ -334,7 +349,8 @@ __device__ __forceinline__ void loader_start(int U, const uint32_t *g, const int
   const uint32_t raw_base = lds_addr(raw);
   const int n = min(n_tiles, RS);
   for (int d = 0; d < n; ++d) {
-    if (U == 4) tile_issue<4, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    if (U == 8) tile_issue<8, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else if (U == 4) tile_issue<4, EXTRA>(g, perm, d, raw_base + d * RB, lane);
     else if (U == 2) tile_issue<2, EXTRA>(g, perm, d, raw_base + d * RB, lane);
     else tile_issue<1, EXTRA>(g, perm, d, raw_base + d * RB, lane);
   }
@@ -355,10 +371,10 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 // whole program issued) it publishes the oldest unpublished tile with the exact count.
 // `land` is the decoder's progress: when it publishes tile t the raw words of tiles 0 .. t+1
 // are in its registers, so the staging slot of tile i is certainly free once land >= i + 1.
-template <int U, bool EXTRA, int AHEAD>
+template <int F, bool EXTRA, int AHEAD>
 __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int RS,
                                             const int *land, int *rland, int lane) {
-  constexpr int OPS = DmaOps<U, EXTRA>::value;
+  constexpr int OPS = DmaOps<F, EXTRA>::value;
   static_assert(OPS * AHEAD <= 63, "vmcnt is 6 bits");
   constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
   const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
@@ -383,7 +399,7 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
       }
       continue;
     }
-    tile_issue<U, EXTRA>(g, perm, issued, rb, lane);
+    tile_issue<F, EXTRA>(g, perm, issued, rb, lane);
     ++issued;
     rb = (rb + RB == raw_end) ? raw_base : rb + RB;
     if (issued - pub > AHEAD) {
@@ -400,33 +416,59 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
 // prog = tiles 0 .. prog-1 are consumed by the sweep, their ring slots are free.
 // LDS accesses of one wave execute in order and LDS is coherent within the CU, so
 // "write slot -> store land" / "load land -> read slot" need no barrier.
-// raw words of one tile in the decoder's registers
+// one tile in the decoder's registers: control word, byte offset of every operand's value,
+// 8 x label of every record, canonical arcs (only with per-arc extras)
 template <int U, bool EXTRA>
 struct RawRegs {
   uint32_t ctl;
-  uint32_t rc[U];
+  uint32_t opoff[U];
+  uint32_t lab8[U];
   int32_t pm[EXTRA ? U : 1];
 };
-template <int U, bool EXTRA>
-__device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<U, EXTRA> &w) {
+template <int F, bool EXTRA>
+__device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<fmt_u(F), EXTRA> &w) {
+  constexpr int U = fmt_u(F);
+  uint32_t rc[U];
+  if (F == 8) {
+    const v4u x = *(const lds_v4u *)(uintptr_t)(rb + lane * 16);
+    w.ctl = x.x;
+    const uint32_t r0 = x.y, r1 = __builtin_amdgcn_alignbit(x.z, x.y, 24), r2 = __builtin_amdgcn_alignbit(x.w, x.z, 16),
+                   r3 = x.w >> 8;
+    const uint32_t r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      w.opoff[j] = (r[j % 4] << 3) & 0xfff8u;   // state (13 bits) x 8
+      w.lab8[j] = (r[j % 4] >> 10) & 0x3ff8u;   // label (11 bits) x 8
+    }
+    if (EXTRA) {
+      const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 1024 + lane * 16);
+      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
+    }
+    return;
+  }
   w.ctl = *(const lds_u32 *)(uintptr_t)(rb + lane * 4);
   if (U == 4) {
     const v4u v = *(const lds_v4u *)(uintptr_t)(rb + 256 + lane * 16);
-    w.rc[0] = v.x; w.rc[1 % U] = v.y; w.rc[2 % U] = v.z; w.rc[3 % U] = v.w;
+    rc[0] = v.x; rc[1 % U] = v.y; rc[2 % U] = v.z; rc[3 % U] = v.w;
     if (EXTRA) {
       const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 256 + 1024 + lane * 16);
       w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
     }
   } else if (U == 2) {
     const v2u v = *(const lds_v2u *)(uintptr_t)(rb + 256 + lane * 8);
-    w.rc[0] = v.x; w.rc[1 % U] = v.y;
+    rc[0] = v.x; rc[1 % U] = v.y;
     if (EXTRA) {
       const v2u a = *(const lds_v2u *)(uintptr_t)(rb + 768 + lane * 8);
       w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y;
     }
   } else {
-    w.rc[0] = *(const lds_u32 *)(uintptr_t)(rb + 256 + lane * 4);
+    rc[0] = *(const lds_u32 *)(uintptr_t)(rb + 256 + lane * 4);
     if (EXTRA) w.pm[0] = (int)*(const lds_u32 *)(uintptr_t)(rb + 512 + lane * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    w.opoff[j] = rc[j] & 0xffffu;
+    w.lab8[j] = (rc[j] >> 16) << 3;
   }
 }
 
@@ -434,24 +476,25 @@ __device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<U, EXTR
 // fewer, busier waves): it keeps AHEAD tiles in flight itself -- self_start() at kernel
 // entry, one issue per iteration -- and a counted wait replaces the rland flag.  The
 // staging ring then has AHEAD + 1 slots.
-template <int U, bool EXTRA, int AHEAD>
+template <int F, bool EXTRA, int AHEAD>
 __device__ __forceinline__ void self_start_u(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int lane) {
   constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
   const uint32_t raw_base = lds_addr(raw);
   const int last = max(n_tiles - 1, 0);
 #pragma unroll
   for (int d = 0; d < AHEAD; ++d)  // short programs copy their last tile again: the count stays constant
-    tile_issue<U, EXTRA>(g, perm, min(d, last), raw_base + d * RB, lane);
+    tile_issue<F, EXTRA>(g, perm, min(d, last), raw_base + d * RB, lane);
 }
 template <bool EXTRA, int AHEAD>
 __device__ __forceinline__ void self_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
                                            int lane) {
-  if (U == 4) self_start_u<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  if (U == 8) self_start_u<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  else if (U == 4) self_start_u<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
   else if (U == 2) self_start_u<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
   else self_start_u<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
 }
 
-template <int U, bool EXTRA, bool SELF, int AHEAD>
+template <int F, bool EXTRA, bool SELF, int AHEAD>
 __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, int RS, const int *rland,
                                              const uint32_t *g, const int32_t *perm,
                                              uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
@@ -460,7 +503,8 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     if (SELF) vm_wait<0>();
     return;
   }
-  constexpr int OPS = DmaOps<U, EXTRA>::value;
+  constexpr int U = fmt_u(F);
+  constexpr int OPS = DmaOps<F, EXTRA>::value;
   constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
   constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
   const uint32_t th_base = lds_addr(th_);
@@ -478,7 +522,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     if (SELF) {
       // one more tile goes in flight (past the end the last tile is copied again into a slot
       // nobody reads, so that the count stays exact); then at most AHEAD are
-      tile_issue<U, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
+      tile_issue<F, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
       ++issue_next;
       rb_issue = (rb_issue + RB == raw_end) ? raw_base : rb_issue + RB;
       vm_wait<OPS * AHEAD>();
@@ -492,7 +536,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
   };
   auto gather_weights = [&](const RawRegs<U, EXTRA> &w, v2f (&tw)[U]) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + ((w.rc[j] >> 16) << 3));
+    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + w.lab8[j]);
   };
   // iteration t: `cur` = raw words of tile t, `tw` = its label weights (LDS gathers issued
   // one iteration earlier); fetches the raw words of tile t+1 into `nxt` and, at the end,
@@ -501,13 +545,13 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     // past the end this reads a stale staging slot whose contents are never used
     rb = (rb + RB == raw_end) ? raw_base : rb + RB;
     wait_raw(min(t + 2, n_tiles));
-    raw_fetch<U, EXTRA>(rb, lane, nxt);
+    raw_fetch<F, EXTRA>(rb, lane, nxt);
     asm volatile("" ::: "memory");
     // --- control word and operand addresses: the packer's byte offsets + the array's base
     const uint32_t w0 = cur.ctl + val_base;
     uint32_t oa[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) oa[j] = (cur.rc[j] & 0xffffu) + val_base;
+    for (int j = 0; j < U; ++j) oa[j] = cur.opoff[j] + val_base;
     // --- the ring slot must be free: tile t - R consumed
     while (__builtin_expect(t - freed >= R, 0)) {
       freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
@@ -548,7 +592,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
   RawRegs<U, EXTRA> ra, rbb;
   v2f ta[U], tb[U];
   wait_raw(1);
-  raw_fetch<U, EXTRA>(rb, lane, ra);
+  raw_fetch<F, EXTRA>(rb, lane, ra);
   gather_weights(ra, ta);
   // two iterations per trip so that the register roles alternate without copies
   for (int t = 0; t < n_tiles; t += 2) {
@@ -691,6 +735,7 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
                                           float2 *val, const float2 *th, const Extra ex, int lane) {
   int *prog = flags, *land = flags + 1, *rland = flags + 2;
   if (role == 0) {
+    if (U == 8) U = 4;  // the sweep only sees decoded tiles
     if (wide) {
       if (U == 4) tile_sweep<4, true>(n_tiles, ring, R, prog, land, lane);
       else if (U == 2) tile_sweep<2, true>(n_tiles, ring, R, prog, land, lane);
@@ -701,11 +746,13 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
       else tile_sweep<1, false>(n_tiles, ring, R, prog, land, lane);
     }
   } else if (role == 1) {
-    if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    if (U == 8) tile_decoder<8, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
     else if (U == 2) tile_decoder<2, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
     else tile_decoder<1, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
   } else if (!SELF) {
-    if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    if (U == 8) tile_loader<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
     else if (U == 2) tile_loader<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
     else tile_loader<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
   }
@@ -1003,7 +1050,7 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
   if (tid == 0) v[m.sink] = 0.0f;
   __syncthreads();
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
-  const int U = m.bwd_u, ST = 64 * (1 + U);
+  const int F = m.bwd_u, U = fmt_u(F), ST = fmt_words(F);  // program format, slots per lane, words per tile
   const uint32_t *prog = lat.bwd_stream + m.bwd_off;
   const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
   constexpr int kNone = 0x7fffffff;
@@ -1033,6 +1080,17 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
   // the words of tile T+1 are loaded while tile T is computed
   struct VitTile { uint32_t ctl; int cas[4]; uint32_t rcs[4]; };
   auto load_tile = [&](int T, VitTile &t) {
+    if (F == 8) {  // compact tile: control word + four 24-bit records per lane
+      const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
+      t.ctl = x.x;
+      const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t.cas[j] = perm[(size_t)T * 256 + lane * 4 + j];
+        t.rcs[j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);  // as a 32-bit record
+      }
+      return;
+    }
     t.ctl = prog[(size_t)T * ST + lane];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -24,6 +24,7 @@ struct Opts {
   int n_threads = 0;
   int slots_per_lane = 0;  // 0 = choose per lattice and direction
   int group_mode = 0;      // 0 = choose, 1 = narrow, 2 = wide
+  bool no_compact = false; // keep 32-bit records
 };
 
 struct Lat {
@@ -35,6 +36,7 @@ struct Lat {
   std::vector<int32_t> row_ptr;  // n_rows + 1, relative
   std::vector<uint32_t> fwd, bwd;
   std::vector<int32_t> fwd_perm, bwd_perm;  // per tile slot: relative canonical arc id or -1
+  bool fwd_compact = false, bwd_compact = false;
   int fwd_tiles = 0, bwd_tiles = 0, fwd_u = 4, bwd_u = 4, fwd_wide = 0, bwd_wide = 0, scratch_rows = 0, sink = 0, n_reach = 0, depth = 0, n_dp = 0;
   int err = NFST_OK;
 };
@@ -68,8 +70,8 @@ struct Piece {
 struct TileCount { int tiles = 0, wide = 0, scratch = 0; };  // wide: tiles whose largest group exceeds 8 lanes
 
 template <class ArcsOf, class Other>
-void emit_level(const std::vector<int32_t> &states, int U, int max_g, uint32_t null_label, int n_rows, ArcsOf arcs_of,
-                Other other, const std::vector<int32_t> &list, const std::vector<int32_t> &label,
+void emit_level(const std::vector<int32_t> &states, int U, int max_g, bool compact, uint32_t null_label, int n_rows,
+                ArcsOf arcs_of, Other other, const std::vector<int32_t> &list, const std::vector<int32_t> &label,
                 std::vector<uint32_t> *stream, std::vector<int32_t> *perm, TileCount &count) {
   const int cap = (1 << max_g) * U;
   const uint32_t null_rec = null_label << 16, unit_label = null_label + 1;
@@ -151,8 +153,24 @@ void emit_level(const std::vector<int32_t> &states, int U, int max_g, uint32_t n
       }
       if (stream) {
         for (int l = 0; l < 64; ++l) ctl[l] |= ((uint32_t)gmax << 23) | (any_accum ? (1u << 26) : 0u);
-        stream->insert(stream->end(), ctl, ctl + 64);
-        stream->insert(stream->end(), rec.begin(), rec.end());
+        if (!compact) {
+          stream->insert(stream->end(), ctl, ctl + 64);
+          stream->insert(stream->end(), rec.begin(), rec.end());
+        } else {
+          // compact tile (U = 4, labels < 2048): 16 bytes per lane = control word + four 24-bit
+          // records (state id 13 bits | label 11 bits) -- one 16-byte LDS-DMA per tile
+          for (int l = 0; l < 64; ++l) {
+            uint32_t r24[4];
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t x = rec[(size_t)l * 4 + j];
+              r24[j] = ((x & 0xffffu) >> 3) | ((x >> 16) << 13);
+            }
+            stream->push_back(ctl[l]);
+            stream->push_back(r24[0] | (r24[1] << 24));
+            stream->push_back((r24[1] >> 8) | (r24[2] << 16));
+            stream->push_back((r24[2] >> 16) | (r24[3] << 8));
+          }
+        }
         perm->insert(perm->end(), pm.begin(), pm.end());
       }
       ++count.tiles;
@@ -241,8 +259,8 @@ void schedule(Lat &L, int vocab, const Opts &o) {
         if ((o.group_mode == 1 && wide) || (o.group_mode == 2 && !wide)) continue;
         TileCount c;
         for (int t = 1; t <= D; ++t) {
-          if (backward) emit_level(by_height[t], us[q], wide ? 6 : 3, null_label, n, out_of, dst_of, out_list, L.label, nullptr, nullptr, c);
-          else emit_level(by_depth[t], us[q], wide ? 6 : 3, null_label, n, in_of, src_of, in_list, L.label, nullptr, nullptr, c);
+          if (backward) emit_level(by_height[t], us[q], wide ? 6 : 3, false, null_label, n, out_of, dst_of, out_list, L.label, nullptr, nullptr, c);
+          else emit_level(by_depth[t], us[q], wide ? 6 : 3, false, null_label, n, in_of, src_of, in_list, L.label, nullptr, nullptr, c);
         }
         if (wide && c.wide == 0 && o.group_mode != 2) continue;  // same program as the narrow one
         const double cost = (double)c.tiles * (330.0 + 55.0 * us[q] + (wide ? 60.0 : 0.0)) + 450.0 * c.wide;
@@ -253,10 +271,14 @@ void schedule(Lat &L, int vocab, const Opts &o) {
   pick(true, L.bwd_u, L.bwd_wide);
   pick(false, L.fwd_u, L.fwd_wide);
   L.fwd.clear(); L.bwd.clear(); L.fwd_perm.clear(); L.bwd_perm.clear();
+  // programs with four slots per lane use the compact tile when the labels fit 11 bits
+  const bool fits = vocab + 2 <= 2048 && !o.no_compact;
+  L.bwd_compact = fits && L.bwd_u == 4;
+  L.fwd_compact = fits && L.fwd_u == 4;
   TileCount cb, cf;
   for (int t = 1; t <= D; ++t) {
-    emit_level(by_height[t], L.bwd_u, L.bwd_wide ? 6 : 3, null_label, n, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, cb);
-    emit_level(by_depth[t], L.fwd_u, L.fwd_wide ? 6 : 3, null_label, n, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, cf);
+    emit_level(by_height[t], L.bwd_u, L.bwd_wide ? 6 : 3, L.bwd_compact, null_label, n, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, cb);
+    emit_level(by_depth[t], L.fwd_u, L.fwd_wide ? 6 : 3, L.fwd_compact, null_label, n, in_of, src_of, in_list, L.label, &L.fwd, &L.fwd_perm, cf);
   }
   L.bwd_tiles = cb.tiles;
   L.fwd_tiles = cf.tiles;
@@ -281,6 +303,7 @@ Opts read_opts(const nfst_pack_opts *o) {
     r.n_threads = o->n_threads;
     r.slots_per_lane = o->slots_per_lane;
     r.group_mode = o->group_mode;
+    r.no_compact = o->reserved1 == 1;
   }
   return r;
 }
@@ -315,7 +338,8 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
     m[NFST_META_FWD_OFF] = (int32_t)fw; m[NFST_META_FWD_TILES] = L.fwd_tiles;
     m[NFST_META_BWD_OFF] = (int32_t)bw; m[NFST_META_BWD_TILES] = L.bwd_tiles;
     m[NFST_META_SINK] = L.sink; m[NFST_META_N_REACH] = L.n_reach; m[NFST_META_DEPTH] = L.depth;
-    m[NFST_META_N_DP] = L.n_dp; m[NFST_META_FWD_U] = L.fwd_u | (L.fwd_wide << 8); m[NFST_META_BWD_U] = L.bwd_u | (L.bwd_wide << 8);
+    m[NFST_META_N_DP] = L.n_dp; m[NFST_META_FWD_U] = (L.fwd_compact ? 8 : L.fwd_u) | (L.fwd_wide << 8);
+    m[NFST_META_BWD_U] = (L.bwd_compact ? 8 : L.bwd_u) | (L.bwd_wide << 8);
     m[NFST_META_FWD_SLOT_OFF] = (int32_t)fs; m[NFST_META_BWD_SLOT_OFF] = (int32_t)bs;
     rows += L.n_rows; arcs += (int64_t)L.src.size(); dp += L.n_dp;
     // tile sizes are multiples of 64 words, so every lattice's stream starts on a

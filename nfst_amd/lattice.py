@@ -46,8 +46,8 @@ class LatticeBatch:
 
     # ---------------------------------------------------------------- construction
     @staticmethod
-    def _opts(n_threads=0, slots_per_lane=0, group_mode=0):
-        return _lib.PackOpts(int(n_threads), int(slots_per_lane), int(group_mode), 0)
+    def _opts(n_threads=0, slots_per_lane=0, group_mode=0, no_compact=False):
+        return _lib.PackOpts(int(n_threads), int(slots_per_lane), int(group_mode), 1 if no_compact else 0)
 
     @classmethod
     def _from_handle(cls, handle, device) -> "LatticeBatch":

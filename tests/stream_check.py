@@ -22,8 +22,11 @@ def replay(lat, b, direction, theta, extra=None):
         off, tiles, U, slot0, start = (int(m[_lib.META_BWD_OFF]), int(m[_lib.META_BWD_TILES]), int(m[_lib.META_BWD_U]) & 0xFF,
                                        int(m[_lib.META_BWD_SLOT_OFF]), int(m[_lib.META_SINK]))
     wide = (int(m[_lib.META_FWD_U if direction == "fwd" else _lib.META_BWD_U]) >> 8) & 1
+    compact = U == 8  # format code 8: 16 bytes per lane = control word + four 24-bit records
+    if compact:
+        U = 4
     assert U in (1, 2, 4) and off % 64 == 0
-    ST = 64 * (1 + U)
+    ST = 256 if compact else 64 * (1 + U)
     src = lat.arc_src.cpu().numpy(); dst = lat.arc_dst.cpu().numpy(); lab = lat.arc_label.cpu().numpy()
     n_lds = max(n_rows, int(lat.max_rows))  # + scratch rows of partial groups
     val = np.full(n_lds, -np.inf)
@@ -34,8 +37,15 @@ def replay(lat, b, direction, theta, extra=None):
     owner = {}  # scratch row -> the state whose arcs its partial group sums
     for T in range(tiles):
         base = off + T * ST
-        ctl = s[base: base + 64]
-        rec = s[base + 64: base + ST].reshape(64, U)
+        if compact:
+            t4 = s[base: base + 256].reshape(64, 4).astype(np.uint64)
+            ctl = t4[:, 0].astype(np.uint32)
+            r24 = np.stack([t4[:, 1] & 0xFFFFFF, ((t4[:, 1] >> 24) | (t4[:, 2] << 8)) & 0xFFFFFF,
+                            ((t4[:, 2] >> 16) | (t4[:, 3] << 16)) & 0xFFFFFF, (t4[:, 3] >> 8) & 0xFFFFFF], axis=1)
+            rec = (((r24 & 0x1FFF) << 3) | ((r24 >> 13) << 16)).astype(np.uint32)  # as 32-bit records
+        else:
+            ctl = s[base: base + 64]
+            rec = s[base + 64: base + ST].reshape(64, U)
         pm = perm[slot0 + T * 64 * U: slot0 + (T + 1) * 64 * U].reshape(64, U)
         gmax = int(ctl[0] >> 23) & 7
         assert np.all(((ctl >> 23) & 7) == gmax)

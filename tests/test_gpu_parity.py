@@ -124,7 +124,8 @@ def _mixed_batch():
     ]
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4)])
+@pytest.mark.parametrize("opts", [dict(), dict(slots_per_lane=1), dict(slots_per_lane=2), dict(slots_per_lane=4),
+                                  dict(slots_per_lane=4, no_compact=True)])
 def test_forward_backward_matches_oracle(dev, opts):
     lats = _mixed_batch()
     theta = synth.label_scores(7, 64)
@@ -250,7 +251,8 @@ def test_viterbi_bit_exact(dev):
     star = synth._finish(204, V, src, lab, dst)
     theta = synth.label_scores(4, V)
     best, path, arcs = O.viterbi(star.n_rows, star.src, star.label, star.dst, theta[star.label], 4000)
-    for opts in (dict(group_mode=1), dict(group_mode=2), dict(group_mode=1, slots_per_lane=1), dict(group_mode=2, slots_per_lane=1)):
+    for opts in (dict(group_mode=1), dict(group_mode=2), dict(group_mode=1, slots_per_lane=1), dict(group_mode=2, slots_per_lane=1),
+                 dict(group_mode=1, slots_per_lane=4, no_compact=True)):
         lat = LatticeBatch.from_synth([star], device=dev, **opts)
         r = ops.viterbi(lat, torch.from_numpy(theta), pad=PAD)
         n = int(r.lengths[0])

@@ -103,9 +103,10 @@ def test_huge_degree_state_is_split_into_continuation_pieces():
     r = O.forward_backward(l.n_rows, l.src, l.dst, theta[l.label].astype(np.float64))
     for U in (1, 2, 4):
         for mode in (0, 1, 2):  # packer's choice, narrow groups (tree of partial groups + combine), wide groups
-            lat = LatticeBatch.from_synth([l], slots_per_lane=U, group_mode=mode)
-            assert np.allclose(replay(lat, 0, "bwd", theta), r["logbeta"], atol=1e-9)
-            assert np.allclose(replay(lat, 0, "fwd", theta), r["logalpha"], atol=1e-9)
+            for nc in (False, True):  # compact (24-bit records, U = 4 only) and 32-bit records
+                lat = LatticeBatch.from_synth([l], slots_per_lane=U, group_mode=mode, no_compact=nc)
+                assert np.allclose(replay(lat, 0, "bwd", theta), r["logbeta"], atol=1e-9)
+                assert np.allclose(replay(lat, 0, "fwd", theta), r["logalpha"], atol=1e-9)
             if mode == 1:  # 200 arcs > 2 x 8 lanes x U: scratch rows are in use
                 assert lat.max_rows > l.n_rows
     lat = LatticeBatch.from_synth([l], slots_per_lane=1)  # 200 in-arcs > 64 lanes x 1 slot
