@@ -145,7 +145,7 @@ constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 
 // word + four 24-bit records (state 13 bits | label 11 bits)
 __host__ __device__ constexpr int fmt_u(int F) { return F == 8 ? 4 : F; }
 __host__ __device__ constexpr int fmt_words(int F) { return F == 8 ? 256 : 64 * (1 + F); }
-constexpr int kMaxRing = 8, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
+constexpr int kMaxRing = 12, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
@@ -654,7 +654,7 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   };
   uint32_t sb = ring_base;  // slot of the tile that is fetched next
   // iteration T: `cur` = tile T with its uniform flags in `cu`; `nxt` receives tile T+1
-  auto step = [&](int T, const TileDec<U> &cur, uint32_t cu, TileDec<U> &nxt, uint32_t &cu_nxt, bool publish) {
+  auto step = [&](int T, const TileDec<U> &cur, uint32_t cu, TileDec<U> &nxt, uint32_t &cu_nxt) {
     // --- operand gathers: the head of the dependency chain
     v2f vv[U];
 #pragma unroll
@@ -709,7 +709,7 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
       }
     }
     // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
-    if (publish || R < 6) lds_flag_store(prog, T + 2);
+    lds_flag_store(prog, T + 2);  // every tile: the decoder's hand-shake latency matters more than the store
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (WIDE) cu_nxt = (uint32_t)__builtin_amdgcn_readfirstlane(nxt.w0);
@@ -721,9 +721,9 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   uint32_t ca = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane(da.w0) : 0u, cb = 0;
   // two iterations per trip so that the register roles alternate without copies
   for (int T = 0; T < n_tiles; T += 2) {
-    step(T, da, ca, db, cb, false);
+    step(T, da, ca, db, cb);
     if (T + 1 >= n_tiles) break;
-    step(T + 1, db, cb, da, ca, true);
+    step(T + 1, db, cb, da, ca);
   }
 }
 
