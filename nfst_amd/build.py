@@ -1,7 +1,8 @@
 """Builds the HIP library in-tree: ``python -m nfst_amd.build``.
 
 One ``hipcc --offload-arch=gfx950`` command over ``csrc/pack.cpp`` (host
-scheduler) and ``csrc/kernels.hip`` (kernels + C-ABI launchers) ->
+scheduler) and ``csrc/kernels.hip`` (C-ABI launchers; the kernels are in the
+headers it includes: semiring, tile pipeline, forward-backward, path kernels) ->
 ``nfst_amd/lib/libnfst_hip.so``.  hipcc cross-compiles without a GPU.
 """
 import os
@@ -12,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "pack.cpp"), os.path.join(HERE, "csrc", "kernels.hip")]
 HDR = os.path.join(ROOT, "include", "nfst_hip.h")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("semiring.h", "tile_pipeline.h", "fb_kernels.h", "path_kernels.h")]
 OUT = os.path.join(HERE, "lib", "libnfst_hip.so")
 
 
@@ -19,7 +21,7 @@ def is_stale() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + [HDR])
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + DEPS + [HDR])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

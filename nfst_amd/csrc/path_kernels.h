@@ -1,0 +1,649 @@
+// path_kernels.h -- Viterbi, posterior sampling, path scoring, per-step gathers, sequence scoring, IWAE
+// Part of the single translation unit kernels.hip (device code in an anonymous namespace).
+#pragma once
+
+// ------------------------------------------------------------------ Viterbi
+// max-plus run of the by-source tile program by one wave (float32 values, back pointers
+// -- canonical arc and next state -- in LDS; the program is read straight from global
+// memory), then lane 0 walks the best path inside LDS.  Ties keep the arc with the smallest
+// canonical id, i.e. the smallest label.
+__device__ __forceinline__ void vit_take(float &bv, int &ba, int &bn, float ov, int oa, int on) {
+  if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; bn = on; }  // bn: the arc's other end
+}
+
+// Wave 0 runs the program; waves 1 .. 3 run ahead of it and pull the tiles it will read
+// (program words, slot -> arc map, per-arc extras) into the L2 cache, throttled by wave 0's
+// progress counter in LDS, so that its dependent loads are L2 hits instead of HBM misses.
+constexpr int kVitThreads = 256, kVitAhead = 12;
+__global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_scores sc, float *best,
+                                                         int32_t *paths, int32_t *path_arcs,
+                                                         int32_t *lengths, int max_len, int pad) {
+  extern __shared__ float2 lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Meta m = load_meta(lat.meta, b);
+  float *v = (float *)lds;
+  int *bp = (int *)(v + lat.max_rows);       // back pointer: best arc out of the state
+  int *ns = bp + lat.max_rows;               // ... and the state it leads to
+  float *tl = (float *)(ns + lat.max_rows);  // [V] label scores
+  int *progress = (int *)(tl + lat.vocab);
+  const float *tg = sc.theta + (size_t)sc.theta_stride * b;
+  for (int i = tid; i < lat.max_rows; i += kVitThreads) { v[i] = kNegInf; bp[i] = -1; }  // incl. scratch rows
+  for (int i = tid; i < lat.vocab; i += kVitThreads) tl[i] = tg[i];
+  if (tid == 0) *progress = 0;
+  __syncthreads();
+  if (tid == 0) v[m.sink] = 0.0f;
+  __syncthreads();
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  const int F = m.bwd_u, U = fmt_u(F), ST = fmt_words(F);  // program format, slots per lane, words per tile
+  const uint32_t *prog = lat.bwd_stream + m.bwd_off;
+  const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
+  constexpr int kNone = 0x7fffffff;
+  if (wv > 0) {
+    const bool extras = arc_w != nullptr || sc.arc_scores != nullptr;
+    float sink_f = 0.0f;
+    int sink_i = 0;
+    for (int T = wv - 1; T < m.bwd_tiles; T += kVitThreads / 64 - 1) {
+      while (T > lds_flag_load(progress) + kVitAhead) __builtin_amdgcn_s_sleep(8);
+      // one 128-byte line per lane
+      const int prog_lines = (ST * 4 + 127) / 128, perm_lines = (64 * U * 4 + 127) / 128;
+      if (lane < prog_lines) sink_i += (int)prog[(size_t)T * ST + min(lane * 32, ST - 1)];
+      if (!extras) {
+        if (lane < perm_lines) sink_i += perm[(size_t)T * 64 * U + min(lane * 32, 64 * U - 1)];
+      } else {
+        for (int j = 0; j < U; ++j) {
+          const int ca = perm[(size_t)T * 64 * U + lane * U + j];
+          if (ca >= 0) {
+            if (arc_w) sink_f += arc_w[ca];
+            if (sc.arc_scores) sink_f += sc.arc_scores[ca];
+          }
+        }
+      }
+    }
+    if (sink_f == 1.2345e-33f && sink_i == 0x12345678) best[b] = 0.0f;  // keeps the loads alive, never true
+  } else {
+  // the words of tile T+1 are loaded while tile T is computed
+  struct VitTile { uint32_t ctl; int cas[4]; uint32_t rcs[4]; };
+  auto load_tile = [&](int T, VitTile &t) {
+    if (F == 8) {  // compact tile: control word + four 24-bit records per lane
+      const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
+      t.ctl = x.x;
+      const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t.cas[j] = perm[(size_t)T * 256 + lane * 4 + j];
+        t.rcs[j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);  // as a 32-bit record
+      }
+      return;
+    }
+    t.ctl = prog[(size_t)T * ST + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jj = min(j, U - 1);
+      t.cas[j] = perm[(size_t)T * 64 * U + lane * U + jj];
+      t.rcs[j] = prog[(size_t)T * ST + 64 + lane * U + jj];
+    }
+  };
+  VitTile cur, nxt;
+  if (m.bwd_tiles > 0) load_tile(0, cur);
+  for (int T = 0; T < m.bwd_tiles; ++T) {
+    load_tile(min(T + 1, m.bwd_tiles - 1), nxt);
+    const uint32_t ctl = cur.ctl;
+    int cas[4];
+    uint32_t rcs[4];
+    float xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cas[j] = (j < U) ? cur.cas[j] : -1; rcs[j] = cur.rcs[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xs[j] = 0.0f;
+      if (cas[j] >= 0) {
+        if (arc_w) xs[j] += arc_w[cas[j]];
+        if (sc.arc_scores) xs[j] += sc.arc_scores[cas[j]];
+      }
+    }
+    float bv = kNegInf;
+    int ba = kNone, bn = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int other = (int)((rcs[j] & 0xffffu) >> 3);
+      if (cas[j] >= 0) vit_take(bv, ba, bn, tl[rcs[j] >> 16] + xs[j] + v[other], cas[j], other);
+      // a unit-label record stands for what row `other` holds -- the state's own earlier pieces
+      // (carry) or a scratch row of a partial group: its best arc competes as such
+      else if (j < U && (int)(rcs[j] >> 16) == lat.vocab + 1 && bp[other] >= 0) vit_take(bv, ba, bn, v[other], bp[other], ns[other]);
+    }
+    const int gl = (int)((ctl >> 20) & 7u);
+    const int gmax = (int)((__builtin_amdgcn_readfirstlane(ctl) >> 23) & 7u);
+    // segmented max over the state's lanes: quad permutes and row mirrors (DPP), then the
+    // two cross-row stages; every lane of a state ends with the same (value, arc, next state)
+#define NFST_VIT_STAGE(ST, FV, FI)                                          \
+    if (gmax > ST) {                                                        \
+      const float ov = FV(bv);                                              \
+      const int oa = FI(ba), on = FI(bn);                                   \
+      if (gl > ST) vit_take(bv, ba, bn, ov, oa, on);                        \
+    }
+#define NFST_SHFL16(x) __shfl_xor(x, 16)
+#define NFST_SHFL32(x) __shfl_xor(x, 32)
+    NFST_VIT_STAGE(0, dpp_f<0xB1>, dpp_i<0xB1>)
+    NFST_VIT_STAGE(1, dpp_f<0x4E>, dpp_i<0x4E>)
+    NFST_VIT_STAGE(2, dpp_f<0x141>, dpp_i<0x141>)
+    NFST_VIT_STAGE(3, dpp_f<0x140>, dpp_i<0x140>)
+    NFST_VIT_STAGE(4, NFST_SHFL16, NFST_SHFL16)
+    NFST_VIT_STAGE(5, NFST_SHFL32, NFST_SHFL32)
+#undef NFST_VIT_STAGE
+#undef NFST_SHFL16
+#undef NFST_SHFL32
+    if (ctl & (1u << 31)) {
+      const uint32_t sid = (ctl & 0xffffu) >> 3;
+      v[sid] = bv;
+      bp[sid] = (ba == kNone) ? -1 : ba;
+      ns[sid] = bn;
+    }
+    // LDS accesses of one wave execute in order: the next tile's loads see these stores
+    asm volatile("" ::: "memory");
+    if ((T & 3) == 3) lds_flag_store(progress, T);
+    cur = nxt;
+  }
+  }
+  // lane 0 walks the back pointers inside LDS (arc ids go to the list `pa`, which reuses the
+  // value array); all threads then write the labels
+  int *pa = (int *)v;
+  int *res = progress;  // [0] length, [1] reached the sink
+  if (tid == 0) {
+    best[b] = v[0];
+    int s0 = 0, len = 0;
+    const int cap = min(max_len, m.n_rows);
+    while (s0 != m.sink && len < cap) {
+      const int a = bp[s0];
+      if (a < 0) break;
+      const int nx = ns[s0];
+      pa[len++] = a;  // v[len-1] is dead: only v[0] was needed, and it has been read
+      s0 = nx;
+    }
+    res[0] = len;
+    res[1] = (s0 == m.sink) ? 1 : 0;
+  }
+  __syncthreads();
+  const int len = res[0];
+  if (tid == 0) lengths[b] = res[1] ? len : -1;
+  for (int j = tid; j < max_len; j += kVitThreads) {
+    const int a = j < len ? pa[j] : -1;
+    paths[(size_t)b * max_len + j] = a >= 0 ? lat.arc_label[a] : pad;
+    if (path_arcs) path_arcs[(size_t)b * max_len + j] = a;
+  }
+}
+
+// ------------------------------------------------------------------ sampling
+__device__ __forceinline__ uint32_t mulhilo(uint32_t a, uint32_t b, uint32_t *hi) {
+  const uint64_t p = (uint64_t)a * b;
+  *hi = (uint32_t)(p >> 32);
+  return (uint32_t)p;
+}
+// Philox4x32-10, counter (walk, step, 0, 0), key from seed; first output word -> [0,1)
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t walk, uint32_t step) {
+  uint32_t c0 = walk, c1 = step, c2 = 0, c3 = 0;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int i = 0; i < 10; ++i) {
+    uint32_t hi0, hi1;
+    const uint32_t lo0 = mulhilo(0xD2511F53u, c0, &hi0);
+    const uint32_t lo1 = mulhilo(0xCD9E8D57u, c2, &hi1);
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float arc_score(const float *theta, const float *arc_w,
+                                           const float *arc_scores, int l, int a) {
+  float s = theta[l];
+  if (arc_w) s += arc_w[a];
+  if (arc_scores) s += arc_scores[a];
+  return s;
+}
+
+// One walk per 16-lane row (a DPP "row"): the arcs of the current state are spread over the
+// row's lanes, 16 at a time; probabilities p = w * beta[dst] / beta[state] come from the
+// lattice's beta values staged in LDS, the CDF is an inclusive scan inside the row
+// (row_shr 1, 2, 4, 8 with zero fill) and the first lane with u < cdf wins (arcs with p = 0
+// never do).  A block is 16 walks of one lattice.
+constexpr int kSampleThreads = 256, kWalksPerBlock = kSampleThreads / 16;
+template <int SHIFT>
+__device__ __forceinline__ float row_shr_zero(float v) {  // lane i gets lane i-SHIFT of its row, 0 if there is none
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SHIFT, 0xf, 0xf, true));
+}
+__global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_scores sc,
+                                                           const float2 *beta_me, const double *logz64, int K,
+                                                           int max_len, const float *uniforms, uint64_t seed,
+                                                           int pad, int stage_theta, int32_t *paths, int32_t *path_arcs,
+                                                           int32_t *lengths, float *logq, int32_t *status) {
+  extern __shared__ float2 lds[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r = tid & 15;                                // lane within the row
+  const int k = blockIdx.y * kWalksPerBlock + (tid >> 4);  // this row's walk
+  const Meta m = load_meta(lat.meta, b);
+  const float *theta = sc.theta + (size_t)sc.theta_stride * b;
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  const int32_t *rp = lat.row_ptr + m.row_off + b;
+  float2 *bl = lds;                                      // beta (m, e) of the lattice's rows
+  float *tls = (float *)(bl + lat.max_rows);             // label scores (staged unless the vocabulary is huge)
+  for (int i = tid; i < m.n_rows; i += kSampleThreads) bl[i] = beta_me[m.row_off + i];
+  if (stage_theta) for (int i = tid; i < lat.vocab; i += kSampleThreads) tls[i] = theta[i];
+  __syncthreads();
+  const float *tl = stage_theta ? (const float *)tls : theta;
+  const bool live = k < K;
+  const size_t walk = (size_t)b * K + (live ? k : 0);
+  int32_t *out = paths + walk * max_len;
+  int32_t *outa = path_arcs ? path_arcs + walk * max_len : nullptr;
+  int s = 0, t = 0;
+  float tot = 0.0f;
+  bool ok = true;
+  bool active = live;
+  while (true) {
+    if (active && s == m.sink) active = false;
+    if (active && t >= max_len) { ok = false; active = false; }
+    if (!__any(active)) break;
+    float u = 0.0f;
+    float2 bs = make_float2(1.0f, 0.0f);
+    int a0 = 0, a1 = 0;
+    if (active) {
+      u = uniforms ? uniforms[walk * max_len + t] : philox_uniform(seed, (uint32_t)walk, (uint32_t)t);
+      bs = bl[s];
+      a0 = rp[s];
+      a1 = rp[s + 1];
+    }
+    const float rs = 1.0f / bs.x;
+    const int es = __float_as_int(bs.y);
+    float cum_base = 0.0f, sc_ch = 0.0f, sc_last = 0.0f;
+    int chosen = -1, last = -1, d_ch = 0, d_last = 0;
+    bool more = active;
+    for (int c = a0; __any(more); c += 16) {
+      more = more && c < a1 && chosen < 0;
+      const int a = c + r;
+      float p = 0.0f, x = 0.0f;
+      int d = 0;
+      if (more && a < a1) {
+        const uint32_t sd = lat.arc_sd[a];
+        d = (int)(sd >> 16);
+        if (d != s) {
+          x = tl[lat.arc_l16[a]];
+          if (arc_w) x += arc_w[a];
+          if (sc.arc_scores) x += sc.arc_scores[a];
+          const ME wgt = exp_split(x);
+          const float2 bd = bl[d];
+          p = ldexpf((wgt.m * bd.x) * rs, max(wgt.e + __float_as_int(bd.y) - es, -300));
+        }
+      }
+      float v = p;
+      v += row_shr_zero<1>(v);
+      v += row_shr_zero<2>(v);
+      v += row_shr_zero<4>(v);
+      v += row_shr_zero<8>(v);
+      const float cum = cum_base + v;
+      const int sh = (int)(threadIdx.x & 48);  // first lane of this row within the wave
+      const uint32_t hit = (uint32_t)(__ballot(more && p > 0.0f && u < cum) >> sh) & 0xffffu;
+      const uint32_t pos = (uint32_t)(__ballot(more && p > 0.0f) >> sh) & 0xffffu;
+      const int f = hit ? __builtin_ctz(hit) : 0, l = pos ? 31 - __builtin_clz(pos) : 0;
+      const float x_f = __shfl(x, f, 16), x_l = __shfl(x, l, 16), c_end = __shfl(cum, 15, 16);
+      const int d_f = __shfl(d, f, 16), d_l = __shfl(d, l, 16);
+      if (more) {
+        if (hit) { chosen = c + f; sc_ch = x_f; d_ch = d_f; }
+        else {
+          cum_base = c_end;
+          if (pos) { last = c + l; sc_last = x_l; d_last = d_l; }
+        }
+      }
+    }
+    if (active) {
+      if (chosen < 0) { chosen = last; sc_ch = sc_last; d_ch = d_last; }
+      if (chosen < 0) { ok = false; active = false; }
+      else {
+        if (r == 0) {
+          out[t] = lat.arc_l16[chosen];
+          if (outa) outa[t] = chosen;
+        }
+        tot += sc_ch;
+        s = d_ch;
+        ++t;
+      }
+    }
+  }
+  if (!live) return;
+  if (!ok && r == 0) atomicExch(status, NFST_ERR_LENGTH);
+  if (r == 0) {
+    lengths[walk] = ok ? t : -1;
+    logq[walk] = ok ? (float)((double)tot - logz64[b]) : kNegInf;
+  }
+  for (int j = t + r; j < max_len; j += 16) { out[j] = pad; if (outa) outa[j] = -1; }
+}
+
+__device__ __forceinline__ int find_arc(const int32_t *arc_label, int r0, int r1, int label) {
+  int lo = r0, hi = r1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (arc_label[mid] < label) lo = mid + 1; else hi = mid;
+  }
+  return (lo < r1 && arc_label[lo] == label) ? lo : -1;
+}
+
+__global__ __launch_bounds__(64) void k_score_paths(nfst_batch lat, nfst_scores sc,
+                                                    const int32_t *marks, int K, int max_len,
+                                                    float *path_score, int32_t *end_state) {
+  const int b = blockIdx.x;
+  const int k = blockIdx.y * 64 + threadIdx.x;
+  if (k >= K) return;
+  const Meta m = load_meta(lat.meta, b);
+  const float *theta = sc.theta + (size_t)sc.theta_stride * b;
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  const int32_t *rp = lat.row_ptr + m.row_off + b;
+  const size_t walk = (size_t)b * K + k;
+  const int32_t *mk = marks + walk * max_len;
+  int s = 0;
+  float tot = 0.0f;
+  for (int t = 0; t < max_len; ++t) {
+    const int l = mk[t];
+    const int a = (l >= 0 && l < lat.vocab) ? find_arc(lat.arc_label, rp[s], rp[s + 1], l) : -1;
+    if (a < 0) { tot = kNegInf; s = 0; break; }
+    const int d = lat.arc_dst[a];
+    if (d != s) tot += arc_score(theta, arc_w, sc.arc_scores, l, a);
+    s = d;
+  }
+  path_score[walk] = tot;
+  end_state[walk] = s;
+}
+
+// ------------------------------------------------------------------ per-step gathers
+__global__ void k_step(nfst_batch lat, const int64_t *state, const int64_t *label, int64_t *next,
+                       int K, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)(i / K);
+  const Meta m = load_meta(lat.meta, b);
+  const int64_t s = state[i], l = label[i];
+  int64_t r = 0;
+  if (s >= 0 && s < m.n_rows && l >= 0 && l < lat.vocab) {
+    const int32_t *rp = lat.row_ptr + m.row_off + b;
+    const int a = find_arc(lat.arc_label, rp[s], rp[s + 1], (int)l);
+    if (a >= 0) r = lat.arc_dst[a];
+  }
+  next[i] = r;
+}
+
+// MODE 0: emission mask (0 / weight / -inf); MODE 1: values[row_off + transition[state, l]]
+template <int MODE>
+__global__ __launch_bounds__(64) void k_row_gather(nfst_batch lat, const int64_t *state,
+                                                   const float *values, const int64_t *inp, int pad,
+                                                   int bos, int eos, int has_to_end, float *out,
+                                                   int K) {
+  const int64_t i = blockIdx.x;
+  const int b = (int)(i / K);
+  const Meta m = load_meta(lat.meta, b);
+  const int64_t s = state[i];
+  int r0 = 0, r1 = 0;
+  if (s >= 0 && s < m.n_rows) {
+    const int32_t *rp = lat.row_ptr + m.row_off + b;
+    r0 = rp[s]; r1 = rp[s + 1];
+  }
+  float *o = out + (size_t)i * lat.vocab;
+  for (int l = threadIdx.x; l < lat.vocab; l += 64) {
+    const int a = find_arc(lat.arc_label, r0, r1, l);
+    float v;
+    if (MODE == 0) {
+      v = (a < 0) ? kNegInf : (lat.weighted ? lat.arc_w[a] : 0.0f);
+      if (inp) {
+        const int64_t p = inp[i];
+        const bool ended = (p == eos) || (p == pad);
+        if (l == bos || (ended ? (l != pad) : (l == pad))) v = kNegInf;
+        if (has_to_end && !ended && l != eos) v = kNegInf;
+      }
+    } else {
+      v = values[m.row_off + (a < 0 ? 0 : lat.arc_dst[a])];
+    }
+    o[l] = v;
+  }
+}
+
+__global__ void k_gather_label_scores(nfst_batch lat, nfst_scores sc, float *out) {
+  const int b = blockIdx.y;
+  const Meta m = load_meta(lat.meta, b);
+  const float *theta = sc.theta + (size_t)sc.theta_stride * b;
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  for (int a = m.arc_off + blockIdx.x * blockDim.x + threadIdx.x; a < m.arc_off + m.n_arcs;
+       a += gridDim.x * blockDim.x)
+    out[a] = arc_score(theta, arc_w, sc.arc_scores, lat.arc_label[a], a);
+}
+
+// ------------------------------------------------------------------ sequence scoring
+// One 256-thread workgroup per sequence; each wave takes positions t = wave,
+// wave+4, ...: masked (log-)softmax over V with wave64 shuffles, gather of the
+// realised mark, pad positions contribute 0 (scorers.py:1564-1611).
+__device__ __forceinline__ float seq_mask(int v, int t, int prev, int pad, int bos, int eos,
+                                          int max_length) {
+  float mk = 0.0f;
+  if (t == 0) {
+    if (v == bos || v == pad) mk = kNegInf;
+    return mk;
+  }
+  const bool ended = (prev == eos) || (prev == pad);
+  if (ended ? (v != pad) : (v == pad)) mk = kNegInf;
+  if (v == bos) mk = kNegInf;
+  if (max_length >= 0 && t > max_length && !ended && v != eos) mk = kNegInf;
+  return mk;
+}
+
+// wave64 all-reduce without LDS traffic: quad permutes and row mirrors (DPP) reduce each
+// row of 16 lanes, v_readlane collects the four row results
+__device__ __forceinline__ float read_lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  return (a + b) + (c + d);
+}
+
+// Streaming version for V % 4 == 0, V <= 1024: every wave keeps RB rows in registers
+// (16-byte loads, RB * NV of them in flight per lane -- the kernel is HBM-bound and would be
+// latency-bound with one row at a time), two-pass softmax per row (max, then sum of exp).
+template <int NV, int RB>
+__global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
+                                                         const int64_t *__restrict__ marks, int T, int V,
+                                                         int pad, int bos, int eos, int max_length,
+                                                         float temp, int normalize, float smoothing,
+                                                         float *out) {
+  __shared__ float part[4];
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t *mk = marks + n * T;
+  const float rtemp = 1.0f / temp;
+  // Row-level legality (scorers.py:59-83) only depends on three row flags; which of this lane's
+  // 4 NV columns are illegal under each is a lane constant, one bit per column:
+  //   normal / first row: bos, pad;  after eos or pad: everything but pad;  forced end: everything but eos
+  uint32_t m_norm = 0, m_end = 0, m_force = 0;
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = (c * 64 + lane) * 4 + k;
+      const uint32_t bit = 1u << (c * 4 + k);
+      const bool oob = col >= V;
+      if (oob || col == bos || col == pad) m_norm |= bit;
+      if (oob || col == bos || col != pad) m_end |= bit;
+      if (oob || col == bos || col == pad || col != eos) m_force |= bit;
+    }
+  float acc = 0.0f;
+  for (int t0 = wave * RB; t0 < T; t0 += 4 * RB) {
+    float4 v[RB][NV];
+    int lab[RB], prev[RB];
+    float lraw[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = min(t0 + r, T - 1);  // clamped: rows past the end are loaded but not used
+      const float4 *row = reinterpret_cast<const float4 *>(scores + ((size_t)n * T + t) * V);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const int q = c * 64 + lane;
+        v[r][c] = (4 * q < V) ? row[q] : make_float4(kNegInf, kNegInf, kNegInf, kNegInf);
+      }
+      lab[r] = (int)mk[t];
+      prev[r] = t > 0 ? (int)mk[t - 1] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)  // the realised marks' scores: all RB gathers in flight together (L2 hits)
+      lraw[r] = scores[((size_t)n * T + min(t0 + r, T - 1)) * V + lab[r]];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = t0 + r;
+      if (t >= T) break;
+      float sel;
+      const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
+      const float lx = ((lab[r] == pad ? 0.0f : lraw[r]) + lmsk) / temp + lmsk;
+      sel = lx;
+      if (normalize || smoothing > 0.0f) {
+        const bool first = t == 0;
+        const bool ended = !first && (prev[r] == eos || prev[r] == pad);
+        const bool force = !first && max_length >= 0 && t > max_length && !ended;
+        const uint32_t bad = ended ? m_end : (force ? m_force : m_norm);
+        float mx = kNegInf;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          float *e = reinterpret_cast<float *>(&v[r][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            // the pad column counts as score 0 (scorers.py:1679-1683); it is only legal in `ended` rows
+            const float x = ended ? 0.0f : e[k] * rtemp;
+            e[k] = (bad & (1u << (c * 4 + k))) ? kNegInf : x;
+            mx = fmaxf(mx, e[k]);
+          }
+        }
+        float lse = 0.0f;
+        if (normalize) {
+          mx = wave_max(mx);
+          float sm = 0.0f;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);  // masked / padding columns: exp(-inf) = 0
+          }
+          sm = wave_sum(sm);
+          lse = mx + logf(sm);
+          sel = lx - lse;  // an all -inf row gives NaN, like the reference
+        }
+        if (smoothing > 0.0f) {
+          // training: label-smoothed target (scorers.py:1502-1528, 1584-1592): weight 1 - s on
+          // the realised mark, s / (cnt - 1) on every other legal mark, values clamped to +-1e9
+          float sx = 0.0f, cnt = 0.0f;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (e[k] > kNegInf) { sx += e[k]; cnt += 1.0f; }
+          }
+          sx = wave_sum(sx);
+          cnt = wave_sum(cnt);
+          const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
+          float rest = sx - cnt * lse;  // sum of the legal marks' values ...
+          float others = cnt;
+          if (lx > kNegInf) { rest -= sel; others -= 1.0f; }  // ... other than the realised one
+          sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
+        }
+      }
+      acc += sel * (lab[r] != pad ? 1.0f : 0.0f);
+    }
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+__global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const int64_t *marks,
+                                                      int T, int V, int pad, int bos, int eos,
+                                                      int max_length, float temp, int normalize,
+                                                      float smoothing, float *out) {
+  __shared__ float part[4];
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t *mk = marks + n * T;
+  float acc = 0.0f;
+  for (int t = wave; t < T; t += 4) {
+    const float *row = scores + ((size_t)n * T + t) * V;
+    const int prev = t > 0 ? (int)mk[t - 1] : -1;
+    const int lab = (int)mk[t];
+    float sel;
+    if (normalize) {
+      // online max / sum over the lane's slice, then a wave reduction
+      float mx = kNegInf, sm = 0.0f;
+      for (int v = lane; v < V; v += 64) {
+        const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
+        const float x = ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+        if (x > mx) { sm = sm * expf(mx - x) + 1.0f; mx = x; }
+        else if (x > kNegInf) sm += expf(x - mx);
+      }
+      for (int d = 32; d >= 1; d >>= 1) {
+        const float omx = __shfl_xor(mx, d), osm = __shfl_xor(sm, d);
+        const float nm = fmaxf(mx, omx);
+        const float a = (mx > kNegInf) ? sm * expf(mx - nm) : 0.0f;
+        const float c = (omx > kNegInf) ? osm * expf(omx - nm) : 0.0f;
+        sm = a + c;
+        mx = nm;
+      }
+      const float msk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
+      const float x = ((lab == pad ? 0.0f : row[lab]) + msk) / temp + msk;
+      sel = x - (mx + logf(sm));  // all -inf row: -inf - (-inf + log 0) = NaN, like the reference
+    } else {
+      const float msk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
+      sel = ((lab == pad ? 0.0f : row[lab]) + msk) / temp + msk;
+    }
+    if (smoothing > 0.0f) {
+      // label-smoothed target (scorers.py:1502-1528, 1584-1592)
+      float lse = 0.0f;
+      const float lmsk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
+      const float lx = ((lab == pad ? 0.0f : row[lab]) + lmsk) / temp + lmsk;
+      if (normalize) lse = lx - sel;
+      float sx = 0.0f, cnt = 0.0f;
+      for (int v = lane; v < V; v += 64) {
+        const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
+        const float x = ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+        if (x > kNegInf) { sx += x; cnt += 1.0f; }
+      }
+      sx = wave_sum(sx);
+      cnt = wave_sum(cnt);
+      const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
+      float rest = sx - cnt * lse, others = cnt;
+      if (lx > kNegInf) { rest -= sel; others -= 1.0f; }
+      sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
+    }
+    acc += sel * (lab != pad ? 1.0f : 0.0f);
+  }
+  // every lane of a wave holds the same acc; reduce the 4 waves in a fixed order
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+__global__ void k_iwae(const float *log_p, const float *log_q, int B, int K, float *log_w,
+                       float *log_marginal) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float mx = kNegInf;
+  for (int k = 0; k < K; ++k) {
+    const float w = log_p[(size_t)b * K + k] - log_q[(size_t)b * K + k];
+    log_w[(size_t)b * K + k] = w;
+    mx = fmaxf(mx, w);
+  }
+  float sm = 0.0f;
+  for (int k = 0; k < K; ++k) sm += expf(log_w[(size_t)b * K + k] - mx);
+  log_marginal[b] = (mx + logf(sm)) - logf((float)K);
+}

@@ -1,0 +1,89 @@
+// semiring.h -- (mantissa, exponent) arithmetic, lattice meta data, per-arc extras
+// Part of the single translation unit kernels.hip (device code in an anonymous namespace).
+#pragma once
+
+constexpr int kEZero = -(1 << 28);      // exponent of an exact zero
+constexpr float kNegInf = -__builtin_huge_valf();
+
+struct ME {
+  float m;
+  int e;
+};
+
+// exp(x) = m * 2^e with m in [0.70, 1.42]; x = -inf (or below -9e7) gives zero.
+__device__ __forceinline__ ME exp_split(float x) {
+  ME r;
+  // weights below e^-9e7 count as zero and scores above 9e7 are clamped: exponents then
+  // stay far from the int32 range when they are added up along a path
+  if (!(x > -9.0e7f)) { r.m = 0.0f; r.e = kEZero; return r; }
+  x = fminf(x, 9.0e7f);
+  float kf = rintf(x * 1.44269504088896341f);
+  float t = fmaf(-kf, 0.693145751953125f, x);         // ln2 high part (exact product)
+  t = fmaf(-kf, 1.42860682030941723e-6f, t);          // ln2 low part
+  // exp(t), |t| <= 0.3466: degree-7 Taylor, relative error < 1e-8
+  float p = 1.0f / 5040.0f;
+  p = fmaf(p, t, 1.0f / 720.0f);
+  p = fmaf(p, t, 1.0f / 120.0f);
+  p = fmaf(p, t, 1.0f / 24.0f);
+  p = fmaf(p, t, 1.0f / 6.0f);
+  p = fmaf(p, t, 0.5f);
+  p = fmaf(p, t, 1.0f);
+  p = fmaf(p, t, 1.0f);
+  r.m = p;
+  r.e = (int)kf;
+  return r;
+}
+
+// normalise a sum to mantissa in [0.5, 1).  A zero sum keeps mantissa 0 (frexp(0) = 0,
+// exponent 0): its exponent stays near kEZero, which never wins a max against a real
+// term, so no select is needed.
+__device__ __forceinline__ float2 me_pack(float M, int E) {
+  int ex;
+  float mant = frexpf(M, &ex);
+  return make_float2(mant, __int_as_float(max(E + ex, kEZero)));  // saturates at 2^(-2^28): no wrap-around
+}
+
+// natural log of an (m, e) pair in float64 / float32
+__device__ __forceinline__ double me_log64(float2 v) {
+  if (!(v.x > 0.0f)) return -__builtin_huge_val();
+  return log((double)v.x) + (double)__float_as_int(v.y) * 0.693147180559945309417232;
+}
+__device__ __forceinline__ float me_log32(float2 v) {
+  if (!(v.x > 0.0f)) return kNegInf;
+  return (float)((double)logf(v.x) + (double)__float_as_int(v.y) * 0.693147180559945309417232);
+}
+
+struct Meta {
+  int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_tiles, bwd_off, bwd_tiles, sink, n_reach, depth, n_dp,
+      fwd_u, bwd_u, fwd_wide, bwd_wide, fwd_slot_off, bwd_slot_off;
+};
+__device__ __forceinline__ Meta load_meta(const int32_t *meta, int b) {
+  const int32_t *m = meta + (size_t)b * NFST_META_WORDS;
+  Meta r;
+  r.row_off = m[NFST_META_ROW_OFF]; r.n_rows = m[NFST_META_N_ROWS];
+  r.arc_off = m[NFST_META_ARC_OFF]; r.n_arcs = m[NFST_META_N_ARCS];
+  r.fwd_off = m[NFST_META_FWD_OFF]; r.fwd_tiles = m[NFST_META_FWD_TILES];
+  r.bwd_off = m[NFST_META_BWD_OFF]; r.bwd_tiles = m[NFST_META_BWD_TILES];
+  r.sink = m[NFST_META_SINK]; r.n_reach = m[NFST_META_N_REACH]; r.depth = m[NFST_META_DEPTH];
+  r.n_dp = m[NFST_META_N_DP];
+  // program format code (1, 2, 4: slots per lane; 8: compact tiles), and bit 8: the program has
+  // tiles with groups wider than 8 lanes
+  r.fwd_u = m[NFST_META_FWD_U] & 0xff; r.bwd_u = m[NFST_META_BWD_U] & 0xff;
+  r.fwd_wide = (m[NFST_META_FWD_U] >> 8) & 1; r.bwd_wide = (m[NFST_META_BWD_U] >> 8) & 1;
+  r.fwd_slot_off = m[NFST_META_FWD_SLOT_OFF]; r.bwd_slot_off = m[NFST_META_BWD_SLOT_OFF];
+  return r;
+}
+
+// Extra per-arc log weight (weighted tables and/or caller-supplied arc scores),
+// addressed by canonical arc id.
+struct Extra {
+  const float *arc_w;
+  const float *arc_scores;
+  __device__ __forceinline__ bool any() const { return arc_w != nullptr || arc_scores != nullptr; }
+  __device__ __forceinline__ float at(int a) const {
+    float x = 0.0f;
+    if (arc_w) x += arc_w[a];
+    if (arc_scores) x += arc_scores[a];
+    return x;
+  }
+};

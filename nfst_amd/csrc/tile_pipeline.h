@@ -1,0 +1,683 @@
+// tile_pipeline.h -- tile programs: loader (LDS-DMA), decoder and the single-wave sweep
+// Part of the single translation unit kernels.hip (device code in an anonymous namespace).
+#pragma once
+
+// ---------------------------------------------------------------- tile programs
+// A sweep is a "tile program" laid out by the host packer (pack.cpp, DESIGN.md
+// section 3): a sequence of fixed-size tiles, each one wave-wide unit of work --
+// 64 control words and 64*U arc records (U = 1, 2 or 4 slots per lane).  ONE wave
+// runs one sweep: its LDS accesses are ordered, a tile only reads states that an
+// earlier tile wrote, so a sweep needs no barrier at all, and the alpha and beta
+// sweeps of a lattice run as two independent waves of the workgroup.
+//
+// control word: [0:16) 8 x state id (the byte offset of its value in the alpha / beta array)
+//               [20:23) g: the state's lanes are the 2^g-aligned group of 2^g lanes
+//               [23:26) largest g in this tile (same in every lane)
+//               [26] the tile holds a continuation piece (same in every lane)
+//               [30] continuation piece (its first record is the carry)  [31] leader lane
+//               (stores the state's sum)
+// record:       [0:16) 8 x operand state | [16:32) label (vocab = the null label: weight 0,
+//               vocab + 1 = the unit label of a carry record: weight 1)
+//
+// The program does not depend on DP values, so two helper waves of the workgroup run far
+// ahead of the sweep.  The LOADER copies tiles from HBM into a small staging ring in LDS
+// with global_load_lds (LDS-DMA, no VGPR staging; kDmaAhead tiles in flight, counted
+// s_waitcnt vmcnt) -- issuing an LDS-DMA costs the issuing wave 60-100 cycles, which is
+// why this is a wave of its own.  The DECODER turns every record into what the sweep
+// needs -- the LDS
+// address of the operand and the (mantissa, exponent) weight of the arc, label weight x
+// per-arc extra -- and writes the decoded tile into a ring of R slots in LDS.  The sweep
+// wave reads only decoded tiles: nothing but the dependency chain is left on it.
+//
+// decoded tile, 64 * (1 + 3U) words:
+//   [0, 64)            word 0 per lane: the control word + the LDS address of alpha / beta:
+//                      [0:20) LDS byte address of the state's value, the rest as above
+//   [64, 64 + 64U)     U operand LDS byte addresses per lane
+//   then               (m, e) weights, slots (2k, 2k+1) of all lanes in block k (16 B per lane)
+// tiles the loader keeps in flight (HBM -> LDS by LDS-DMA) and raw-tile staging slots per
+// sweep: deep when a workgroup has a CU's LDS to itself, shallow when two share it
+constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = kDmaAheadShared + 1;
+constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
+constexpr int kRawWordsX = kRawWords + 64 * 4;  // + the slots' canonical arc ids (kernels with per-arc extras)
+constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
+// program format code (meta word, bits 0..7): 1, 2, 4 = slots per lane with 32-bit records and a
+// separate control block; 8 = the compact tile: four slots per lane, 16 bytes per lane = control
+// word + four 24-bit records (state 13 bits | label 11 bits)
+__host__ __device__ constexpr int fmt_u(int F) { return F == 8 ? 4 : F; }
+__host__ __device__ constexpr int fmt_words(int F) { return F == 8 ? 256 : 64 * (1 + F); }
+constexpr int kMaxRing = 12, kMinRing = 3;       // ring slots per sweep (chosen at launch from the LDS budget)
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// Segmented all-reduce of (M, E) partial sums: a lane whose state owns 2^g lanes takes
+// part in stages 0 .. g-1.  Stage partners: lane^1, lane^2 (quad permutes), 7-lane and
+// 15-lane mirrors inside a row (DPP modifiers, no LDS traffic), then lane^16 and
+// lane^32 (shuffles).  GMAX (the tile's largest g) bounds the stages executed.  All
+// lanes of a state end with bitwise the same (M, E): max of exponents, one rescale,
+// then the sum.
+// Segmented all-reduce of (M, E) partial sums: a lane whose state owns 2^g lanes takes
+// part in stages 0 .. g-1.  Stage partners: lane^1, lane^2 (quad permutes), 7-lane and
+// 15-lane mirrors inside a row (DPP modifiers, no LDS traffic), then lane^16 and
+// lane^32 (shuffles).  Stages 0..2 always run (one predicated select each, no
+// branch); stages 3..5 only when the tile's largest g needs them.  All lanes of a state
+// end with bitwise the same (M, E): max of exponents, one rescale, then the sum.
+template <int STAGES>
+__device__ __forceinline__ int seg_max(int Em, int g) {
+  if (STAGES >= 1) { const int o = dpp_i<0xB1>(Em); Em = (g >= 1) ? max(Em, o) : Em; }
+  if (STAGES >= 2) { const int o = dpp_i<0x4E>(Em); Em = (g >= 2) ? max(Em, o) : Em; }
+  if (STAGES >= 3) { const int o = dpp_i<0x141>(Em); Em = (g >= 3) ? max(Em, o) : Em; }
+  if (STAGES >= 4) { const int o = dpp_i<0x140>(Em); Em = (g >= 4) ? max(Em, o) : Em; }
+  if (STAGES >= 5) { const int o = __shfl_xor(Em, 16); Em = (g >= 5) ? max(Em, o) : Em; }
+  if (STAGES >= 6) { const int o = __shfl_xor(Em, 32); Em = (g >= 6) ? max(Em, o) : Em; }
+  return Em;
+}
+template <int STAGES>
+__device__ __forceinline__ float seg_sum(float M, int g) {
+  if (STAGES >= 1) { const float o = dpp_f<0xB1>(M); M = (g >= 1) ? M + o : M; }
+  if (STAGES >= 2) { const float o = dpp_f<0x4E>(M); M = (g >= 2) ? M + o : M; }
+  if (STAGES >= 3) { const float o = dpp_f<0x141>(M); M = (g >= 3) ? M + o : M; }
+  if (STAGES >= 4) { const float o = dpp_f<0x140>(M); M = (g >= 4) ? M + o : M; }
+  if (STAGES >= 5) { const float o = __shfl_xor(M, 16); M = (g >= 5) ? M + o : M; }
+  if (STAGES >= 6) { const float o = __shfl_xor(M, 32); M = (g >= 6) ? M + o : M; }
+  return M;
+}
+// The same reduction for groups of up to 8 lanes with the per-lane select replaced by the
+// execution mask: m[s] = lanes whose state owns more than 2^s lanes (wave masks, computed
+// off the dependency chain); a DPP instruction executed under m[s] updates exactly the
+// lanes that take part in stage s and leaves the others as they are, so a stage is ONE
+// vector instruction.  The scalar moves in between also provide the two wait states a
+// DPP read needs after a vector write.  Returns the group's exponent in E, the sum in M.
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_exec(float &M, int &E, uint64_t m0, uint64_t m1, uint64_t m2) {
+  static_assert(STAGES == 2 || STAGES == 3, "");
+  const int e0 = E;
+  int d;
+  uint64_t sv;
+  if (STAGES == 2) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_sub_u32 %[d], %[e0], %[e]\n\t"
+        "v_ldexp_f32 %[m], %[m], %[d]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(M), [e] "+&v"(E), [d] "=&v"(d), [sv] "=&s"(sv)
+        : [m0] "s"(m0), [m1] "s"(m1), [e0] "v"(e0));
+  } else {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[e], %[e], %[e] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_sub_u32 %[d], %[e0], %[e]\n\t"
+        "v_ldexp_f32 %[m], %[m], %[d]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(M), [e] "+&v"(E), [d] "=&v"(d), [sv] "=&s"(sv)
+        : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [e0] "v"(e0));
+  }
+}
+
+template <int STAGES>
+__device__ __forceinline__ void seg_reduce_n(float &M, int &E, int g) {
+  const int Em = seg_max<STAGES>(E, g);
+  M = seg_sum<STAGES>(ldexpf(M, E - Em), g);
+  E = Em;
+}
+
+__device__ __forceinline__ int lds_flag_load(const int *p) {
+  return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ void lds_flag_store(int *p, int v) {
+  __atomic_store_n(p, v, __ATOMIC_RELAXED);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) v2u lds_v2u;
+typedef __attribute__((address_space(3))) v4u lds_v4u;
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// ---- producer / consumer protocol -------------------------------------------------
+// Two LDS words per sweep, both only grow:
+//   land: tiles 0 .. land-1 are decoded and in the ring (written by the decoder)
+//   prog: tiles 0 .. prog-1 are consumed, their slots are free (written by the sweep)
+// LDS accesses of one wave execute in order and LDS is coherent within the CU, so
+// "write slot -> store land" / "load land -> read slot" need no barrier.
+
+// LDS-DMA (global_load_lds_*): lane i's `bytes` go to LDS address m0 + i*bytes.  Issued
+// from inline asm on purpose: the compiler then keeps no record of a pending LDS-DMA and
+// does not put s_waitcnt vmcnt(0) in front of every LDS access; the counted waits are
+// placed by hand (vm_wait).  In-flight data never lives in registers, so no compiler-made
+// register copy can touch it early.  Only full-wave 4- and 16-byte forms are used (the
+// 12-byte and exec-masked forms do not lay lanes out at lane x size on gfx950).  `nt`: a tile
+// program is read once per launch by one CU (measured: 1-2 % on the whole step).
+__device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void *gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {  // at most N vector-memory operations of this wave stay in flight
+  static_assert(N >= 0 && N <= 63, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS-DMA instructions per tile
+template <int F, bool EXTRA>
+struct DmaOps {
+  static constexpr int value = F == 8 ? (EXTRA ? 2 : 1) : (F == 2 ? 3 : 2) + (EXTRA ? (F == 2 ? 2 : 1) : 0);
+};
+
+// raw staging slot: [64 control words][64 U records]([64 U canonical arc ids]); compact tiles:
+// [64 x (control word, 3 record words)]([256 canonical arc ids])
+template <int F, bool EXTRA>
+__device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *perm, int tile, uint32_t slot_addr, int lane) {
+  constexpr int U = fmt_u(F);
+  const uint32_t *src = g + (size_t)tile * fmt_words(F);
+  const int32_t *q = perm + (size_t)tile * (64 * U);
+  if (F == 8) {
+    lds_dma16(src + lane * 4, slot_addr);
+    if (EXTRA) lds_dma16(q + lane * 4, slot_addr + 1024);
+    return;
+  }
+  lds_dma4(src + lane, slot_addr);
+  if (U == 4) {
+    lds_dma16(src + 64 + lane * 4, slot_addr + 256);
+    if (EXTRA) lds_dma16(q + lane * 4, slot_addr + 256 + 1024);
+  } else if (U == 2) {
+    lds_dma4(src + 64 + lane, slot_addr + 256);
+    lds_dma4(src + 128 + lane, slot_addr + 512);
+    if (EXTRA) { lds_dma4(q + lane, slot_addr + 768); lds_dma4(q + 64 + lane, slot_addr + 1024); }
+  } else {
+    lds_dma4(src + 64 + lane, slot_addr + 256);
+    if (EXTRA) lds_dma4(q + lane, slot_addr + 512);
+  }
+}
+
+// ---- loader wave ------------------------------------------------------------------
+// flags (LDS words, all only grow): rland = raw tiles 0 .. rland-1 have landed in the
+// staging ring; the decoder's `land` (tiles decoded) tells which staging slots are free.
+// part 1 (kernel entry, before anything else): the first ring-full needs no hand-shake,
+// so it is in flight while the workgroup initialises
+template <bool EXTRA>
+__device__ __forceinline__ void loader_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
+                                             int RS, int lane) {
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw);
+  const int n = min(n_tiles, RS);
+  for (int d = 0; d < n; ++d) {
+    if (U == 8) tile_issue<8, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else if (U == 4) tile_issue<4, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else if (U == 2) tile_issue<2, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else tile_issue<1, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+  }
+}
+
+// blocks until at most `tiles` tiles (OPS LDS-DMA instructions each) are in flight;
+// vmcnt takes an immediate, hence the chain
+template <int OPS, int MAXT>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if (MAXT > 0 && tiles >= MAXT) vm_wait<(OPS * MAXT > 63 ? 63 : OPS * MAXT)>();
+  else if (MAXT > 0) wait_tiles_in_flight<OPS, (MAXT > 0 ? MAXT - 1 : 0)>(tiles);
+  else vm_wait<0>();
+}
+
+// part 2: streams the rest of the tile program into the staging ring.  Copies complete
+// in order, so "at most k tiles in flight" means tiles 0 .. issued-k-1 have landed: after
+// an issue the loader waits with k = AHEAD; whenever it cannot issue (ring full, or the
+// whole program issued) it publishes the oldest unpublished tile with the exact count.
+// `land` is the decoder's progress: when it publishes tile t the raw words of tiles 0 .. t+1
+// are in its registers, so the staging slot of tile i is certainly free once land >= i + 1.
+template <int F, bool EXTRA, int AHEAD>
+__device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int RS,
+                                            const int *land, int *rland, int lane) {
+  constexpr int OPS = DmaOps<F, EXTRA>::value;
+  static_assert(OPS * AHEAD <= 63, "vmcnt is 6 bits");
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
+  int issued = min(n_tiles, RS);  // loader_start issued these
+  uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
+  int freed = 0;                  // copy of the decoder's counter
+  int pub = 0;                    // tiles published in rland
+  // nothing to issue right now: wait until half of the unpublished tiles have landed and
+  // publish those (then half of the rest, ...)
+  auto publish_some = [&]() {
+    const int keep = (issued - pub - 1) >> 1;  // tiles that may stay in flight
+    wait_tiles_in_flight<OPS, AHEAD>(keep);
+    pub = issued - keep;
+    lds_flag_store(rland, pub);
+  };
+  while (issued < n_tiles) {
+    if (__builtin_expect(issued - freed >= RS, 0)) {  // ring full: look at the decoder's progress
+      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (issued - freed >= RS) {
+        if (pub < issued) publish_some();
+        else __builtin_amdgcn_s_sleep(1);
+      }
+      continue;
+    }
+    tile_issue<F, EXTRA>(g, perm, issued, rb, lane);
+    ++issued;
+    rb = (rb + RB == raw_end) ? raw_base : rb + RB;
+    if (issued - pub > AHEAD) {
+      vm_wait<OPS * AHEAD>();
+      pub = issued - AHEAD;
+      lds_flag_store(rland, pub);
+    }
+  }
+  while (pub < n_tiles) publish_some();
+}
+
+// ---- decoder wave -----------------------------------------------------------------
+// flags: land = tiles 0 .. land-1 are decoded and in the ring (written here),
+// prog = tiles 0 .. prog-1 are consumed by the sweep, their ring slots are free.
+// LDS accesses of one wave execute in order and LDS is coherent within the CU, so
+// "write slot -> store land" / "load land -> read slot" need no barrier.
+// one tile in the decoder's registers: control word, byte offset of every operand's value,
+// 8 x label of every record, canonical arcs (only with per-arc extras)
+template <int U, bool EXTRA>
+struct RawRegs {
+  uint32_t ctl;
+  uint32_t opoff[U];
+  uint32_t lab8[U];
+  int32_t pm[EXTRA ? U : 1];
+};
+template <int F, bool EXTRA>
+__device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<fmt_u(F), EXTRA> &w) {
+  constexpr int U = fmt_u(F);
+  uint32_t rc[U];
+  if (F == 8) {
+    const v4u x = *(const lds_v4u *)(uintptr_t)(rb + lane * 16);
+    w.ctl = x.x;
+    const uint32_t r0 = x.y, r1 = __builtin_amdgcn_alignbit(x.z, x.y, 24), r2 = __builtin_amdgcn_alignbit(x.w, x.z, 16),
+                   r3 = x.w >> 8;
+    const uint32_t r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      w.opoff[j] = (r[j % 4] << 3) & 0xfff8u;   // state (13 bits) x 8
+      w.lab8[j] = (r[j % 4] >> 10) & 0x3ff8u;   // label (11 bits) x 8
+    }
+    if (EXTRA) {
+      const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 1024 + lane * 16);
+      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
+    }
+    return;
+  }
+  w.ctl = *(const lds_u32 *)(uintptr_t)(rb + lane * 4);
+  if (U == 4) {
+    const v4u v = *(const lds_v4u *)(uintptr_t)(rb + 256 + lane * 16);
+    rc[0] = v.x; rc[1 % U] = v.y; rc[2 % U] = v.z; rc[3 % U] = v.w;
+    if (EXTRA) {
+      const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 256 + 1024 + lane * 16);
+      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
+    }
+  } else if (U == 2) {
+    const v2u v = *(const lds_v2u *)(uintptr_t)(rb + 256 + lane * 8);
+    rc[0] = v.x; rc[1 % U] = v.y;
+    if (EXTRA) {
+      const v2u a = *(const lds_v2u *)(uintptr_t)(rb + 768 + lane * 8);
+      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y;
+    }
+  } else {
+    rc[0] = *(const lds_u32 *)(uintptr_t)(rb + 256 + lane * 4);
+    if (EXTRA) w.pm[0] = (int)*(const lds_u32 *)(uintptr_t)(rb + 512 + lane * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    w.opoff[j] = rc[j] & 0xffffu;
+    w.lab8[j] = (rc[j] >> 16) << 3;
+  }
+}
+
+// SELF: the decoder also does the loader's job (kernels with two workgroups per CU run
+// fewer, busier waves): it keeps AHEAD tiles in flight itself -- self_start() at kernel
+// entry, one issue per iteration -- and a counted wait replaces the rland flag.  The
+// staging ring then has AHEAD + 1 slots.
+template <int F, bool EXTRA, int AHEAD>
+__device__ __forceinline__ void self_start_u(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int lane) {
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw);
+  const int last = max(n_tiles - 1, 0);
+#pragma unroll
+  for (int d = 0; d < AHEAD; ++d)  // short programs copy their last tile again: the count stays constant
+    tile_issue<F, EXTRA>(g, perm, min(d, last), raw_base + d * RB, lane);
+}
+template <bool EXTRA, int AHEAD>
+__device__ __forceinline__ void self_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
+                                           int lane) {
+  if (U == 8) self_start_u<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  else if (U == 4) self_start_u<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  else if (U == 2) self_start_u<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+  else self_start_u<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+}
+
+template <int F, bool EXTRA, bool SELF, int AHEAD>
+__device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, int RS, const int *rland,
+                                             const uint32_t *g, const int32_t *perm,
+                                             uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
+                                             const float2 *th_, const Extra ex, int lane) {
+  if (n_tiles <= 0) {
+    if (SELF) vm_wait<0>();
+    return;
+  }
+  constexpr int U = fmt_u(F);
+  constexpr int OPS = DmaOps<F, EXTRA>::value;
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
+  const uint32_t th_base = lds_addr(th_);
+  const uint32_t val_base = lds_addr(val);
+  const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+  const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
+  uint32_t sb = ring_base;  // decoded slot of tile t
+  uint32_t rb = raw_base;   // staging slot of the tile whose raw words are fetched next
+  uint32_t rb_issue = raw_base + (SELF ? AHEAD * RB : 0);  // SELF: staging slot of the tile issued next
+  int issue_next = AHEAD;                                   // SELF: that tile
+  const int last = n_tiles - 1;
+  int freed = 0, landed = 0;
+  int prog_peek = 0;  // SELF: the sweep's counter as of the previous iteration (per-lane copy)
+  // makes sure the raw words of tile need-1 are in the staging ring (called once per tile, in order)
+  auto wait_raw = [&](int need) {
+    if (SELF) {
+      // one more tile goes in flight (past the end the last tile is copied again into a slot
+      // nobody reads, so that the count stays exact); then at most AHEAD are
+      tile_issue<F, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
+      ++issue_next;
+      rb_issue = (rb_issue + RB == raw_end) ? raw_base : rb_issue + RB;
+      vm_wait<OPS * AHEAD>();
+      return;
+    }
+    while (__builtin_expect(landed < need, 0)) {
+      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(rland));
+      if (landed < need) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  auto gather_weights = [&](const RawRegs<U, EXTRA> &w, v2f (&tw)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + w.lab8[j]);
+  };
+  // iteration t: `cur` = raw words of tile t, `tw` = its label weights (LDS gathers issued
+  // one iteration earlier); fetches the raw words of tile t+1 into `nxt` and, at the end,
+  // issues the gathers of its label weights into `twn`
+  auto step = [&](int t, const RawRegs<U, EXTRA> &cur, v2f (&tw)[U], RawRegs<U, EXTRA> &nxt, v2f (&twn)[U]) {
+    // past the end this reads a stale staging slot whose contents are never used
+    rb = (rb + RB == raw_end) ? raw_base : rb + RB;
+    // the self-loading decoder reads the sweep's counter (LDS) one iteration ahead: in the common
+    // case the check of the ring slot costs no LDS round trip (measured: +3 % arcs/s with two
+    // workgroups per CU; with separate loader waves the extra read costs 1 %, so not there)
+    if (SELF) freed = max(freed, __builtin_amdgcn_readfirstlane(prog_peek));
+    wait_raw(min(t + 2, n_tiles));
+    raw_fetch<F, EXTRA>(rb, lane, nxt);
+    if (SELF) prog_peek = lds_flag_load(prog);
+    asm volatile("" ::: "memory");
+    // --- control word and operand addresses: the packer's byte offsets + the array's base
+    const uint32_t w0 = cur.ctl + val_base;
+    uint32_t oa[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) oa[j] = cur.opoff[j] + val_base;
+    // --- the ring slot must be free: tile t - R consumed
+    while (__builtin_expect(t - freed >= R, 0)) {
+      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
+      if (t - freed >= R) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    *(lds_u32 *)(uintptr_t)(sb + lane * 4) = w0;
+    if (U == 4) *(lds_v4u *)(uintptr_t)(sb + 256 + lane * 16) = v4u{oa[0], oa[1 % U], oa[2 % U], oa[3 % U]};
+    else if (U == 2) *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
+    else *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
+    if (EXTRA) {
+      // per-arc extras: plain loads, waited for in place (lattices with per-arc extras
+      // decode at about one memory latency per tile)
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if (cur.pm[j] >= 0) {
+          const ME x = exp_split(ex.at(cur.pm[j]));
+          tw[j].x *= x.m;
+          tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
+        }
+      }
+    }
+    if (U == 4) {
+      *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+      *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{tw[2 % U].x, tw[2 % U].y, tw[3 % U].x, tw[3 % U].y};
+    } else if (U == 2) {
+      *(lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
+    } else {
+      *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = tw[0];
+    }
+    asm volatile("" ::: "memory");
+    // tile t is decoded; the loader reads the same word: the raw words of tiles 0 .. t+1
+    // are in registers
+    lds_flag_store(land, t + 1);
+    sb = (sb + SB == ring_end) ? ring_base : sb + SB;
+    gather_weights(nxt, twn);
+  };
+  RawRegs<U, EXTRA> ra, rbb;
+  v2f ta[U], tb[U];
+  wait_raw(1);
+  raw_fetch<F, EXTRA>(rb, lane, ra);
+  gather_weights(ra, ta);
+  // two iterations per trip so that the register roles alternate without copies
+  for (int t = 0; t < n_tiles; t += 2) {
+    step(t, ra, ta, rbb, tb);
+    if (t + 1 >= n_tiles) break;
+    step(t + 1, rbb, tb, ra, ta);
+  }
+  if (SELF) vm_wait<0>();  // nothing of the staging ring stays in flight
+}
+
+// decoded tile in the sweep wave's registers
+template <int U>
+struct TileDec {
+  uint32_t w0;
+  uint32_t opa[U];
+  v2f tw[U];
+};
+
+template <int U>
+__device__ __forceinline__ void dec_fetch(uint32_t sb, int lane, TileDec<U> &d) {
+  d.w0 = *(const lds_u32 *)(uintptr_t)(sb + lane * 4);
+  if (U == 4) {
+    const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 256 + lane * 16);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16);
+    const v4f q = *(const lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y; d.opa[2 % U] = a.z; d.opa[3 % U] = a.w;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w}; d.tw[2 % U] = v2f{q.x, q.y}; d.tw[3 % U] = v2f{q.z, q.w};
+  } else if (U == 2) {
+    const v2u a = *(const lds_v2u *)(uintptr_t)(sb + 256 + lane * 8);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w};
+  } else {
+    d.opa[0] = *(const lds_u32 *)(uintptr_t)(sb + 256 + lane * 4);
+    d.tw[0] = *(const lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8);
+  }
+}
+
+// One sum-product sweep, run by ONE wave over the decoded ring.  The sweep is one
+// dependency chain (gather operands -> sum -> reduce over the state's lanes -> store ->
+// next tile's gathers) and a single wave issues one instruction every ~4 cycles, a taken
+// branch costs ~20 and a scalar use of a fresh vector result ~25: an iteration is
+// straight-line code.  It starts with the operand gathers of its tile, fetches the next
+// decoded tile and prepares the stage masks in their shadow, and ends by moving the next
+// tile's wave-uniform flags to a scalar register.
+template <int U, bool WIDE>
+__device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land,
+                                           int lane) {
+  if (n_tiles <= 0) return;
+  constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;  // bytes per ring slot
+  const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+  int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
+  auto wait_landed = [&](int need) {
+    while (__builtin_expect(landed < need, 0)) {
+      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (landed < need) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  uint32_t sb = ring_base;  // slot of the tile that is fetched next
+  int land_peek = 0;        // the decoder's counter as of the previous iteration (per-lane copy of the LDS word)
+  // iteration T: `cur` = tile T with its uniform flags in `cu`; `nxt` receives tile T+1
+  auto step = [&](int T, const TileDec<U> &cur, uint32_t cu, TileDec<U> &nxt, uint32_t &cu_nxt) {
+    // --- operand gathers: the head of the dependency chain
+    v2f vv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)cur.opa[j];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the gathers
+    // --- the next decoded tile.  Past the end of the program this reads a stale slot
+    // whose contents are never used.
+    sb = (sb + SB == ring_end) ? ring_base : sb + SB;
+    // the decoder's counter was read (LDS) during the previous iteration: in the common case the
+    // check costs no LDS round trip
+    landed = max(landed, __builtin_amdgcn_readfirstlane(land_peek));
+    wait_landed(min(T + 2, n_tiles));
+    dec_fetch<U>(sb, lane, nxt);
+    land_peek = lds_flag_load(land);
+    asm volatile("" ::: "memory");
+    // --- what only needs the tile's control word: stage masks (lanes whose state owns
+    // more than 2^s lanes), leader lanes, store address
+    const uint32_t w0 = cur.w0;
+    const int gl = (int)((w0 >> 20) & 7u);
+    lds_v2f *dst = (lds_v2f *)(uintptr_t)(w0 & 0xfffffu);
+    const bool leader = (int)w0 < 0;
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
+                   m2 = __builtin_amdgcn_ballot_w64(gl > 2);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // --- this lane's partial sum with one shared exponent
+    float mt[U];
+    int et[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      mt[j] = cur.tw[j].x * vv[j].x;
+      et[j] = __float_as_int(cur.tw[j].y) + __float_as_int(vv[j].y);
+    }
+    int E = et[0];
+#pragma unroll
+    for (int j = 1; j < U; ++j) E = max(E, et[j]);
+    float M = ldexpf(mt[0], et[0] - E);
+#pragma unroll
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
+    // --- reduce over the state's lanes (max of exponents, one rescale, sum), normalise,
+    // store.  Groups of up to 8 lanes run three stages under execution masks (a stage
+    // nobody takes part in is an empty mask).  Only programs the packer marked WIDE have
+    // tiles with larger groups (flagged wave-uniformly); those take the general path.
+    if (WIDE && __builtin_expect((cu & (1u << 25)) != 0, 0)) {
+      seg_reduce_n<6>(M, E, gl);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    } else {
+      seg_reduce_exec<3>(M, E, m0, m1, m2);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    }
+    // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
+    lds_flag_store(prog, T + 2);  // every tile: the decoder's hand-shake latency matters more than the store
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (WIDE) cu_nxt = (uint32_t)__builtin_amdgcn_readfirstlane(nxt.w0);
+  };
+  wait_landed(1);
+  TileDec<U> da, db;
+  dec_fetch<U>(sb, lane, da);
+  asm volatile("" ::: "memory");
+  uint32_t ca = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane(da.w0) : 0u, cb = 0;
+  // two iterations per trip so that the register roles alternate without copies
+  for (int T = 0; T < n_tiles; T += 2) {
+    step(T, da, ca, db, cb);
+    if (T + 1 >= n_tiles) break;
+    step(T + 1, db, cb, da, ca);
+  }
+}
+
+// role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder.
+// flags: [0] prog [1] land [2] rland
+template <bool EXTRA, bool SELF, int AHEAD>
+__device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *raw, int RS, const uint32_t *g,
+                                          const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
+                                          float2 *val, const float2 *th, const Extra ex, int lane) {
+  int *prog = flags, *land = flags + 1, *rland = flags + 2;
+  if (role == 0) {
+    if (U == 8) U = 4;  // the sweep only sees decoded tiles
+    if (wide) {
+      if (U == 4) tile_sweep<4, true>(n_tiles, ring, R, prog, land, lane);
+      else if (U == 2) tile_sweep<2, true>(n_tiles, ring, R, prog, land, lane);
+      else tile_sweep<1, true>(n_tiles, ring, R, prog, land, lane);
+    } else {
+      if (U == 4) tile_sweep<4, false>(n_tiles, ring, R, prog, land, lane);
+      else if (U == 2) tile_sweep<2, false>(n_tiles, ring, R, prog, land, lane);
+      else tile_sweep<1, false>(n_tiles, ring, R, prog, land, lane);
+    }
+  } else if (role == 1) {
+    if (U == 8) tile_decoder<8, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    else if (U == 2) tile_decoder<2, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+    else tile_decoder<1, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+  } else if (!SELF) {
+    if (U == 8) tile_loader<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else if (U == 2) tile_loader<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else tile_loader<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+  }
+}
+
+__device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64_t stride, int b,
+                                           int V, int tid, int nt) {
+  const float *t = theta + (size_t)stride * b;
+  for (int l = tid; l < V; l += nt) {
+    ME x = exp_split(t[l]);
+    th[l] = make_float2(x.m, __int_as_float(x.e));
+  }
+  if (tid == 0) {
+    th[V] = make_float2(0.0f, __int_as_float(kEZero));  // the null label of empty slots
+    th[V + 1] = make_float2(0.5f, __int_as_float(1));       // weight one: the carry record of a continuation piece
+  }
+}
