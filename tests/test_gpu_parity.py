@@ -494,3 +494,24 @@ def test_forward_backward_is_graph_capturable(dev):
     theta.copy_(theta2)
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(out.logz64, ref_z) and torch.equal(out.posterior, ref_p)
+
+def test_repeated_launches_are_bit_identical(dev):
+    """The loader / decoder / sweep waves synchronise through counters in LDS only: any ordering
+    bug would show up as run-to-run differences.  Every flavour (one lattice per CU, two workgroups
+    per CU with 512 and 256 threads, per-arc extras, wide groups) is launched many times."""
+    theta = torch.from_numpy(synth.label_scores(1, 256)).to(dev)
+    small = [synth.layered_lattice(9000 + i, n_states=30 + 17 * (i % 23), avg_degree=4.0 + (i % 5), vocab=256, width=1 + i % 9,
+                                   span=1 + i % 4) for i in range(700)]
+    cases = [(synth.bench_batch(32), dict()), (small[:300], dict()), (small, dict()), (small, dict(extras=True)),
+             (synth.bench_batch(16), dict(group_mode=2))]
+    for lats, kw in cases:
+        extras = kw.pop("extras", False)
+        lat = LatticeBatch.from_synth(lats, device=dev, **kw)
+        asc = torch.randn(lat.total_arcs, device=dev) * 0.2 if extras else None
+        ref = ops.forward_backward(lat, theta, arc_scores=asc)
+        refb = ops.backward(lat, theta, arc_scores=asc)
+        for _ in range(60):
+            r = ops.forward_backward(lat, theta, arc_scores=asc)
+            assert torch.equal(r.logz64, ref.logz64) and torch.equal(r.posterior, ref.posterior)
+            assert torch.equal(r.logalpha, ref.logalpha) and torch.equal(r.logbeta, ref.logbeta)
+            assert torch.equal(ops.backward(lat, theta, arc_scores=asc).logz64, refb.logz64)
