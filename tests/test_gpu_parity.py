@@ -515,3 +515,23 @@ def test_repeated_launches_are_bit_identical(dev):
             assert torch.equal(r.logz64, ref.logz64) and torch.equal(r.posterior, ref.posterior)
             assert torch.equal(r.logalpha, ref.logalpha) and torch.equal(r.logbeta, ref.logbeta)
             assert torch.equal(ops.backward(lat, theta, arc_scores=asc).logz64, refb.logz64)
+
+def test_large_vocabulary_uses_32_bit_records(dev):
+    """More than 2046 marks do not fit the compact tile's 11-bit label field: the packer must fall
+    back to 32-bit records (format code 4) and the results must not change."""
+    V = 3000
+    lats = [synth.layered_lattice(50 + i, n_states=400 + 90 * i, avg_degree=9.0, vocab=V, width=12, span=5) for i in range(3)]
+    theta = synth.label_scores(6, V)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    assert set((lat.meta_host[:, _lib.META_FWD_U] & 0xFF).tolist()) <= {1, 2, 4}
+    r = ops.forward_backward(lat, torch.from_numpy(theta))
+    v = ops.viterbi(lat, torch.from_numpy(theta), pad=PAD)
+    for b, l in enumerate(lats):
+        o, _ = oracle_fb(l, theta)
+        a0 = int(lat.arc_off[b])
+        assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL * max(1.0, abs(o["logZ"]) / 16)
+        assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
+        best, path, arcs = O.viterbi(l.n_rows, l.src, l.label, l.dst, theta[l.label], 4000)
+        n = int(v.lengths[b])
+        assert n == len(path) and np.float32(best) == v.best.cpu().numpy()[b]
+        assert np.array_equal(v.paths.cpu().numpy()[b, :n], path)
