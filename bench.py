@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
     ap.add_argument("--graph", action="store_true", help="replay a HIP graph of the step instead of launching from Python "
                     "(measured slower on ROCm 7.2: 67.8 vs 59.2 us per step)")
+    ap.add_argument("--torch-sum", action="store_true", help="reduce the loss with torch.sum instead of the kernel's fused total")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
     args = ap.parse_args()
@@ -146,14 +147,21 @@ def main():
     arcs = int(lat.n_dp_arcs.sum())
     alg_bytes = lat.algorithmic_bytes("forward_backward")
 
-    state = {"out": None}
+    state = {"out": None, "i": 0}
+    # sum_b log Z[b] comes out of the kernel itself (atomic adds into one of three rotating slots):
+    # the loss of a step needs no reduction kernel
+    total = torch.zeros(3, dtype=torch.float64, device=dev)
+    fused = args.mode != "bwd" and not args.torch_sum
 
     def run():
         # outputs are allocated by the first call and overwritten afterwards (steady state)
+        slot = state["i"] % 3
+        state["i"] += 1
+        kw = dict(total=total, total_slot=slot) if fused else {}
         if args.mode == "fb":
-            state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=True, want_posterior=True, out=state["out"])
+            state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=True, want_posterior=True, out=state["out"], **kw)
         elif args.mode == "fb_sweeps_only":
-            state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=False, want_posterior=False, out=state["out"])
+            state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=False, want_posterior=False, out=state["out"], **kw)
         else:
             return ops.backward(lat, theta, want_logbeta=False)
         return state["out"]
@@ -162,8 +170,9 @@ def main():
 
     def reduce_loss(r):
         """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously: the collective
-        of step t overlaps the sweep of step t+1; at most one is in flight"""
-        loss = r.logz64.sum()
+        of step t overlaps the sweep of step t+1; at most one is in flight (its slot of `total` is
+        cleared two launches later)"""
+        loss = total[(state["i"] - 1) % 3] if fused else r.logz64.sum()
         if world > 1:
             if pending["work"] is not None:
                 pending["work"].wait()
@@ -250,7 +259,8 @@ def main():
                                    f"(layer width {args.width}), alpha+beta+logZ+arc posteriors",
                        "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
                        "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()), "host_pack_s": pack_s,
-                       "launch": "hip_graph_replay" if use_graph else "python"},
+                       "launch": "hip_graph_replay" if use_graph else "python",
+                       "loss": "fused in the kernel (atomic adds)" if fused else "torch.sum"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,

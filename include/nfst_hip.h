@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define NFST_ABI_VERSION 1
+#define NFST_ABI_VERSION 2
 
 /* error codes */
 #define NFST_OK 0
@@ -209,10 +209,14 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
  * posterior[a] = exp(alpha[src] + score + beta[dst] - log Z) in canonical arc
  * order (= d log Z / d score[a]); grad_theta (optional, [B, V] float32) receives the
  * posteriors summed per label (d log Z / d theta[b, l]).
+ * logz_total (optional, 3 doubles, zero-initialised once by the caller): the launch adds every
+ * lattice's log Z to logz_total[total_slot] (atomic adds: the summation order is not fixed) and
+ * clears logz_total[(total_slot + 1) % 3] for the next launch -- the loss of a training step
+ * without a reduction kernel; use total_slot = step % 3.
  */
 int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, float *logalpha,
                           float *logbeta, double *logz64, float *logz32, float *posterior,
-                          float *grad_theta, float *beta_me, void *stream);
+                          float *grad_theta, float *beta_me, double *logz_total, int32_t total_slot, void *stream);
 
 /*
  * Viterbi: best[b] = max path score (float32), paths [B, max_len] int32 labels

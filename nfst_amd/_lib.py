@@ -72,7 +72,7 @@ def _load():
         "nfst_packed_free": (None, [vp]),
         "nfst_lds_bytes": (i64, [BP]),
         "nfst_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp]),
-        "nfst_forward_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "nfst_forward_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]),
         "nfst_viterbi": (C.c_int, [BP, SP, vp, vp, vp, vp, i32, i32, vp]),
         "nfst_sample_paths": (C.c_int, [BP, SP, vp, vp, i32, i32, vp, u64, i32, vp, vp, vp, vp, vp, vp]),
         "nfst_score_paths": (C.c_int, [BP, SP, vp, i32, i32, vp, vp, vp]),
@@ -91,7 +91,7 @@ def _load():
 
 
 lib, EXPORTS = _load()
-if lib.nfst_abi_version() != 1:
+if lib.nfst_abi_version() != 2:
     raise ImportError("libnfst_hip.so ABI version mismatch; rebuild with `python -m nfst_amd.build --force`")
 
 

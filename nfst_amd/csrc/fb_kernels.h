@@ -96,7 +96,8 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 template <int NT, bool EXTRA>
 __global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, int R, int RS, float *__restrict__ logalpha, float *__restrict__ logbeta,
-    double *__restrict__ logz64, float *__restrict__ logz32, float *__restrict__ posterior,
+    double *__restrict__ logz64, float *__restrict__ logz32, double *__restrict__ logz_total, int total_slot,
+    float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   if (tid == 0) {
     const double z = me_log64(zme);
     if (logz64) logz64[b] = z;
+    if (logz_total) {
+      atomicAdd(&logz_total[total_slot], z);
+      if (b == 0) logz_total[(total_slot + 1) % 3] = 0.0;  // the slot of the next launch
+    }
     if (logz32) logz32[b] = (float)z;
   }
   const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;

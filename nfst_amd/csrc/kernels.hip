@@ -142,11 +142,12 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
 
 int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, float *logalpha,
                           float *logbeta, double *logz64, float *logz32, float *posterior,
-                          float *grad_theta, float *beta_me, void *stream) {
+                          float *grad_theta, float *beta_me, double *logz_total, int32_t total_slot, void *stream) {
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
+  if (logz_total && (total_slot < 0 || total_slot > 2)) return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
@@ -159,7 +160,8 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   {                                                                                                     \
     if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
     hipLaunchKernelGGL((k_forward_backward<NT, EX>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,      \
-                       (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, posterior, \
+                       (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, logz_total,    \
+                       (int)total_slot, posterior,                                                      \
                        grad_theta, (float2 *)beta_me);                                                  \
   }
   // 1024 threads: loaders + decoders + sweeps and 10 more waves for the posterior pass (deep);

@@ -83,11 +83,13 @@ class ForwardBackwardResult(NamedTuple):
 
 def forward_backward(lat: LatticeBatch, theta, arc_scores=None, want_alpha_beta=True, want_posterior=True,
                      want_grad_theta=False, want_me=False,
-                     out: Optional[ForwardBackwardResult] = None) -> ForwardBackwardResult:
+                     out: Optional[ForwardBackwardResult] = None, total=None, total_slot: int = 0) -> ForwardBackwardResult:
     """alpha/beta sweeps, exact log Z and arc posteriors (the quantity the
     reference only estimates by IWAE, modules/estimatros.py:33-44).  ``out`` (a
     previous result of the same batch and flags) is overwritten in place instead of
-    allocating new outputs -- the steady state of a training loop."""
+    allocating new outputs -- the steady state of a training loop.  ``total`` (a float64 tensor
+    of 3 zeros, owned by the caller) receives sum_b log Z[b] in ``total[total_slot]`` without a
+    reduction kernel; pass ``total_slot = step % 3`` (the launch clears the next slot)."""
     _need_gpu(lat)
     sc, keep = _scores(lat, theta, arc_scores)
     dev = lat.device
@@ -105,8 +107,11 @@ def forward_backward(lat: LatticeBatch, theta, arc_scores=None, want_alpha_beta=
         post = torch.empty(lat.total_arcs, **f32) if want_posterior else None
         gth = torch.empty((lat.n_lattices, lat.vocab), **f32) if want_grad_theta else None
         me = torch.empty((lat.total_rows, 2), **f32) if want_me else None
+    if total is not None and (total.dtype != torch.float64 or total.numel() != 3 or total.device != z64.device):
+        raise ValueError("`total` must be a float64 tensor of 3 elements on the batch's device")
     check(lib.nfst_forward_backward(C.byref(lat.c_struct()), C.byref(sc), _ptr(la), _ptr(lb), _ptr(z64), _ptr(z32),
-                                    _ptr(post), _ptr(gth), _ptr(me), _stream()), "nfst_forward_backward")
+                                    _ptr(post), _ptr(gth), _ptr(me), _ptr(total), int(total_slot), _stream()),
+          "nfst_forward_backward")
     return ForwardBackwardResult(z32, z64, la, lb, post, gth, me)
 
 

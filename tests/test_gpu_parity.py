@@ -535,3 +535,20 @@ def test_large_vocabulary_uses_32_bit_records(dev):
         n = int(v.lengths[b])
         assert n == len(path) and np.float32(best) == v.best.cpu().numpy()[b]
         assert np.array_equal(v.paths.cpu().numpy()[b, :n], path)
+
+def test_fused_log_z_total(dev):
+    """nfst_forward_backward can add every lattice's log Z into one of three rotating slots
+    (the loss of a training step without a reduction kernel) and clears the next slot."""
+    lats = _mixed_batch()
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    total = torch.zeros(3, dtype=torch.float64, device=dev)
+    out = None
+    for step in range(7):
+        theta = torch.from_numpy(synth.label_scores(step, 64)).to(dev)
+        out = ops.forward_backward(lat, theta, out=out, total=total, total_slot=step % 3)
+        want = float(out.logz64.sum())
+        got = total.cpu().numpy()
+        assert abs(got[step % 3] - want) <= 1e-9 * max(1.0, abs(want))
+        assert got[(step + 1) % 3] == 0.0
+    with pytest.raises(ValueError):
+        ops.forward_backward(lat, theta, total=torch.zeros(3, device=dev))
