@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
     ap.add_argument("--graph", action="store_true", help="replay a HIP graph of the step instead of launching from Python "
                     "(measured slower on ROCm 7.2: 67.8 vs 59.2 us per step)")
+    ap.add_argument("--event-every", type=int, default=8, help="HIP events around every n-th timed launch")
     ap.add_argument("--torch-sum", action="store_true", help="reduce the loss with torch.sum instead of the kernel's fused total")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
@@ -216,12 +217,18 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # kernel duration: HIP events around every `every`-th launch of the timed region (events are
+    # extra commands between back-to-back launches: bracketing each one costs ~1 us per step)
+    every = max(1, args.event_every)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(0, args.steps, every)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
+        timed = i % every == 0
+        if timed:
+            ev[i // every][0].record()
         r = launch()
-        ev[i][1].record()
+        if timed:
+            ev[i // every][1].record()
         loss = reduce_loss(r)
     if pending["work"] is not None:
         pending["work"].wait()
