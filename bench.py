@@ -173,11 +173,12 @@ def main():
         """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously: the collective
         of step t overlaps the sweep of step t+1; at most one is in flight (its slot of `total` is
         cleared two launches later)"""
-        loss = total[(state["i"] - 1) % 3] if fused else r.logz64.sum()
+        slot = (state["i"] - 1) % 3
+        loss = total[slot:slot + 1] if fused else r.logz64.sum()
         if world > 1:
             if pending["work"] is not None:
                 pending["work"].wait()
-            loss, pending["work"] = all_reduce_loss(loss, async_op=True)
+            loss, pending["work"] = all_reduce_loss(loss, async_op=True, inplace=fused)  # in the slot itself
         return loss
 
     # --graph: a step is launched by replaying a HIP graph of the forward-backward kernel (the
@@ -267,7 +268,7 @@ def main():
                        "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
                        "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()), "host_pack_s": pack_s,
                        "launch": "hip_graph_replay" if use_graph else "python",
-                       "loss": "fused in the kernel (atomic adds)" if fused else "torch.sum"},
+                       "loss_reduction": "fused in the kernel (atomic adds)" if fused else "torch.sum"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,

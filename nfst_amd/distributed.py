@@ -30,16 +30,18 @@ def shard_lattices(n_arcs: Sequence[int], world_size: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
-def all_reduce_loss(loss: torch.Tensor, async_op: bool = False):
+def all_reduce_loss(loss: torch.Tensor, async_op: bool = False, inplace: bool = False):
     """Sum a scalar (float64 recommended) over ranks; 8 bytes, latency only.
 
     ``async_op=True`` returns ``(tensor, work)``: the collective runs on the backend's
     own stream and the caller's stream only waits at ``work.wait()`` -- the loss of
     step t is needed for logging, not by step t+1, so the next step's kernels need not
-    queue behind the (latency-bound) all-reduce."""
+    queue behind the (latency-bound) all-reduce.  ``inplace=True`` reduces into ``loss`` itself
+    (e.g. a slot of the kernel's fused total) instead of a copy."""
     work = None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        loss = loss.clone()
+        if not inplace:
+            loss = loss.clone()
         work = dist.all_reduce(loss, op=dist.ReduceOp.SUM, async_op=async_op)
     return (loss, work) if async_op else loss
 
