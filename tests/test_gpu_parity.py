@@ -552,3 +552,65 @@ def test_fused_log_z_total(dev):
         assert got[(step + 1) % 3] == 0.0
     with pytest.raises(ValueError):
         ops.forward_backward(lat, theta, total=torch.zeros(3, device=dev))
+
+def test_snips_shaped_batch(dev):
+    """BASELINE configs[2]: a batch of 64 tagging-shaped lattices (S ~ 400..1500, V ~ 250, long and
+    narrow: a few tag states per token position, up to ~750 positions)."""
+    V = 250
+    rng = np.random.default_rng(64)
+    lats = [synth.layered_lattice(3000 + i, n_states=int(rng.integers(400, 1501)), avg_degree=float(rng.choice([3.0, 5.0, 8.0])),
+                                  vocab=V, width=int(rng.choice([2, 3, 6, 8])), span=int(rng.choice([1, 2])), max_degree=40)
+            for i in range(64)]
+    theta = synth.label_scores(64, V, mean=-1.5, std=0.8)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    assert int(lat.depth.max()) >= 500
+    r = ops.forward_backward(lat, torch.from_numpy(theta))
+    v = ops.viterbi(lat, torch.from_numpy(theta), pad=PAD)
+    for b in range(0, 64, 3):
+        l = lats[b]
+        o, _ = oracle_fb(l, theta)
+        r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
+        tol = TOL * max(1.0, abs(o["logZ"]) / 16)
+        assert abs(float(r.logz64[b]) - o["logZ"]) <= tol
+        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tol)
+        assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 1e-5
+        best, path, arcs = O.viterbi(l.n_rows, l.src, l.label, l.dst, theta[l.label], 4000)
+        n = int(v.lengths[b])
+        assert n == len(path) and np.float32(best) == v.best.cpu().numpy()[b]
+        assert np.array_equal(v.paths.cpu().numpy()[b, :n], path)
+    # every lattice: posteriors of the arcs leaving the start state sum to one
+    post = r.posterior.cpu().numpy()
+    for b, l in enumerate(lats):
+        a0 = int(lat.arc_off[b])
+        assert abs(post[a0:a0 + l.n_arcs][l.src == 0].sum() - 1.0) <= 1e-5
+
+
+def test_sampling_and_viterbi_with_bf16_scores(dev):
+    """BASELINE configs[4]: posterior sampling + Viterbi on a transliteration-shaped lattice with
+    the scores rounded to bfloat16 (the engine accumulates in float32 either way).  Against the
+    float32-score oracle: |log Z| difference <= 5e-2; against the oracle run on the
+    rounded scores: the usual 1e-5 and bit-exact indices."""
+    V = 64
+    x = list(range(10, 22)); y = list(range(30, 41))
+    l = synth.edit_lattice(x, y, vocab=V, seed=5)
+    theta = synth.label_scores(12, V, mean=-1.0, std=0.7)
+    theta_bf = torch.from_numpy(theta).to(torch.bfloat16).to(torch.float32).numpy()
+    lat = LatticeBatch.from_synth([l], device=dev)
+    o32, _ = oracle_fb(l, theta)
+    obf, scbf = oracle_fb(l, theta_bf)
+    r = ops.forward_backward(lat, torch.from_numpy(theta_bf))
+    assert abs(float(r.logz64[0]) - obf["logZ"]) <= TOL
+    assert abs(float(r.logz64[0]) - o32["logZ"]) <= 5e-2
+    v = ops.viterbi(lat, torch.from_numpy(theta_bf), pad=PAD)
+    best, path, arcs = O.viterbi(l.n_rows, l.src, l.label, l.dst, theta_bf[l.label], 4000)
+    n = int(v.lengths[0])
+    assert n == len(path) and np.float32(best) == v.best.cpu().numpy()[0]
+    assert np.array_equal(v.paths.cpu().numpy()[0, :n], path) and np.array_equal(v.arcs.cpu().numpy()[0, :n], arcs)
+    K, T = 16, int(lat.depth.max()) + 1
+    u = np.random.default_rng(3).random((1, K, T)).astype(np.float32)
+    s = ops.sample_paths(lat, torch.from_numpy(theta_bf), K, max_len=T, uniforms=torch.from_numpy(u), pad=PAD)
+    ref = O.sample_paths(l.n_rows, l.src, l.label, l.dst, scbf, obf["logbeta"], u[0].astype(np.float64), PAD)
+    safe = ref["margin"] > 1e-5
+    assert safe.sum() >= K - 2
+    assert np.array_equal(s.paths.cpu().numpy()[0][safe], ref["paths"][safe])
+    assert np.max(np.abs(s.logq.cpu().numpy()[0][safe] - ref["logq"][safe])) <= 2e-5
