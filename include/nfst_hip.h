@@ -274,6 +274,21 @@ int nfst_emission_mask(const nfst_batch *lat, const int64_t *state, const int64_
 int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *state,
                      float *out, int32_t k, void *stream);
 
+/*
+ * Fused lattice side of one proposal-sampler step (Sampler.stateful_sample, samplers.py:243-297;
+ * left_to_right_score, scorers.py:340-366; mask_out_invalid, 1037-1054 + 59-83; beta-logit gather,
+ * 581-593; update_fsa_state, 683-690): for every walker n (lattice n / k)
+ *   logits = (pad_masking(scores[n, :]) [+ values[next state]] + emission row + legality masks) / temperature
+ *   symbol = forced[n], or the first mark (in id order) whose CDF exceeds uniforms[n]
+ *   logq = logits[symbol] - logsumexp(logits), logz = that logsumexp (optional), next_state as nfst_step.
+ * inp (the previous symbols) may be NULL: no bos / pad / eos legality masks then.  values is row-indexed
+ * [total_rows] (e.g. beta in the domain the caller's scorer expects) or NULL.  vocab <= 4096.
+ */
+int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_t *inp, const float *scores,
+                       const float *values, int32_t pad, int32_t bos, int32_t eos, int32_t has_to_end, float temperature,
+                       const float *uniforms, const int64_t *forced, int64_t *symbol, float *logq, float *logz,
+                       int64_t *next_state, int32_t k, void *stream);
+
 /* out[a] = theta[(theta_stride * b) + label[a]] (+ arc_w[a]) (+ arc_scores[a]) */
 int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, float *out,
                              void *stream);

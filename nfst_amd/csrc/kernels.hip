@@ -253,6 +253,25 @@ int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *
   return hip_status(hipGetLastError());
 }
 
+int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_t *inp, const float *scores,
+                       const float *values, int32_t pad, int32_t bos, int32_t eos, int32_t has_to_end, float temperature,
+                       const float *uniforms, const int64_t *forced, int64_t *symbol, float *logq, float *logz,
+                       int64_t *next_state, int32_t k, void *stream) {
+  int rc = check_batch(lat);
+  if (rc) return rc;
+  if (!state || !scores || !symbol || !logq || !next_state || k <= 0 || !(temperature > 0.0f)) return NFST_ERR_ARG;
+  if (!uniforms && !forced) return NFST_ERR_ARG;
+  if (pad < 0 || pad >= lat->vocab) return NFST_ERR_ARG;
+  if (lat->vocab > kStepMaxVocab) return NFST_ERR_LIMIT;
+  const int64_t n = (int64_t)lat->n_lattices * k;
+  const int64_t lds = (int64_t)kStepWaves * 2 * lat->vocab * 4;
+  if ((rc = set_lds(k_proposal_step, lds))) return rc;
+  hipLaunchKernelGGL(k_proposal_step, dim3((unsigned)((n + kStepWaves - 1) / kStepWaves)), dim3(64 * kStepWaves), (size_t)lds,
+                     (hipStream_t)stream, *lat, state, inp, scores, values, (int)pad, (int)bos, (int)eos, (int)has_to_end,
+                     temperature, uniforms, forced, symbol, logq, logz, next_state, (int)k, n);
+  return hip_status(hipGetLastError());
+}
+
 int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, float *out, void *stream) {
   int rc = check_batch(lat);
   if (rc) return rc;

@@ -647,3 +647,96 @@ __global__ void k_iwae(const float *log_p, const float *log_q, int B, int K, flo
   for (int k = 0; k < K; ++k) sm += expf(log_w[(size_t)b * K + k] - mx);
   log_marginal[b] = (mx + logf(sm)) - logf((float)K);
 }
+
+// ------------------------------------------------------------------ fused proposal step
+// Fused lattice side of one proposal-sampler step (Sampler.stateful_sample, samplers.py:243-297):
+// logits = (pad_masking(scores) [+ values of the next states] + emission row + legality masks)
+// / temperature -> logsumexp, inverse-CDF sample on a supplied uniform (or the forced symbol),
+// its log probability, next state.  One wave per walker; the walker's row of logits and next
+// states lives in LDS (V <= kStepMaxVocab).
+constexpr int kStepMaxVocab = 4096, kStepWaves = 4;
+__global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
+    nfst_batch lat, const int64_t *state, const int64_t *inp, const float *scores, const float *values, int pad, int bos,
+    int eos, int has_to_end, float temperature, const float *uniforms, const int64_t *forced, int64_t *symbol,
+    float *logq, float *logz, int64_t *next_state, int K, int64_t n_walkers) {
+  extern __shared__ float2 lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n = (int64_t)blockIdx.x * kStepWaves + wave;
+  if (n >= n_walkers) return;
+  const int V = lat.vocab;
+  float *xs = (float *)lds + (size_t)wave * 2 * V;  // logits of the walker's row
+  int *nx = (int *)(xs + V);                          // next state per mark (-1: no arc)
+  const int b = (int)(n / K);
+  const Meta m = load_meta(lat.meta, b);
+  const int64_t s = state[n];
+  int r0 = 0, r1 = 0;
+  if (s >= 0 && s < m.n_rows) {
+    const int32_t *rp = lat.row_ptr + m.row_off + b;
+    r0 = rp[s]; r1 = rp[s + 1];
+  }
+  // LDS accesses of one wave execute in order: no barrier between the phases
+  for (int v = lane; v < V; v += 64) { xs[v] = kNegInf; nx[v] = -1; }
+  for (int a = r0 + lane; a < r1; a += 64) {  // the state's arcs carry distinct marks
+    const int l = lat.arc_label[a];
+    xs[l] = lat.weighted ? lat.arc_w[a] : 0.0f;
+    nx[l] = lat.arc_dst[a];
+  }
+  const int64_t prev = inp ? inp[n] : -1;
+  const bool ended = inp && (prev == eos || prev == pad);
+  const float rt = 1.0f / temperature;
+  float mx = kNegInf;
+  for (int v = lane; v < V; v += 64) {
+    float x = xs[v];
+    if (inp) {  // bos / pad / eos legality (scorers.py:59-83)
+      if (v == bos || (ended ? (v != pad) : (v == pad))) x = kNegInf;
+      if (has_to_end && !ended && v != eos) x = kNegInf;
+    }
+    if (x > kNegInf) {
+      float sc = (v == pad) ? 0.0f : scores[(size_t)n * V + v];  // pad_masking (scorers.py:182-187)
+      if (values) sc += values[m.row_off + nx[v]];
+      x = (sc + x) * rt;
+    }
+    xs[v] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = wave_max(mx);
+  float sm = 0.0f;
+  if (mx > kNegInf)
+    for (int v = lane; v < V; v += 64) sm += __expf(xs[v] - mx);
+  sm = wave_sum(sm);
+  const float lz = (mx > kNegInf) ? mx + logf(sm) : kNegInf;  // no legal mark: log z = -inf, symbol = pad, log q = -inf
+  int sym = -1;
+  if (!(mx > kNegInf)) {
+    sym = -1;
+  } else if (forced) {
+    sym = (int)forced[n];
+  } else {
+    const float u = uniforms[n];
+    float base = 0.0f;
+    int last = -1;
+    for (int c = 0; c < V && sym < 0; c += 64) {
+      const int v = c + lane;
+      const float p = (v < V) ? __expf(xs[v] - lz) : 0.0f;
+      float cum = p;
+      for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(cum, d);
+        if (lane >= d) cum += o;
+      }
+      cum += base;
+      const uint64_t hit = __ballot(p > 0.0f && u < cum), pos = __ballot(p > 0.0f);
+      if (hit) sym = c + __builtin_ctzll(hit);
+      else {
+        if (pos) last = c + 63 - __builtin_clzll(pos);
+        base = __shfl(cum, 63);
+      }
+    }
+    if (sym < 0) sym = last;  // u beyond the rounded total: the last legal mark
+  }
+  if (lane == 0) {
+    const bool ok = sym >= 0 && sym < V;
+    symbol[n] = ok ? sym : pad;
+    logq[n] = ok ? xs[sym] - lz : kNegInf;
+    if (logz) logz[n] = lz;
+    next_state[n] = (ok && nx[sym] >= 0) ? nx[sym] : 0;  // like nfst_step: 0 where the table has no arc
+  }
+}

@@ -267,6 +267,52 @@ def beta_logits(lat: LatticeBatch, values: torch.Tensor, state: torch.Tensor, k:
     return out
 
 
+class ProposalStep(NamedTuple):
+    symbol: torch.Tensor      # [N] int64
+    logq: torch.Tensor        # [N] float32: log probability of the symbol
+    logz: torch.Tensor        # [N] float32: logsumexp of the masked logits
+    next_state: torch.Tensor  # [N] int64
+
+
+def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, k: int = 1,
+                  inp: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None, pad: int = 0, bos: int = 1,
+                  eos: int = 2, has_to_end: bool = False, temperature: float = 1.0,
+                  uniforms: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None) -> ProposalStep:
+    """One step of the reference's proposal sampler on the lattice side, fused
+    (Sampler.stateful_sample, samplers.py:243-297: left_to_right_score + mask_out_invalid +
+    Categorical sample / log_prob + update_fsa_state).  ``scores`` [N, V] are the proposal
+    network's outputs for this step; ``values`` (row-indexed, e.g. beta) are added through the
+    next-state gather of scorers.py:581-593; ``uniforms`` [N] drive the inverse-CDF draw, or
+    ``forced`` [N] gives the symbols to evaluate."""
+    _need_gpu(lat)
+    state = _walkers(lat, state, k, "state")
+    N = state.shape[0]
+    dev = lat.device
+    scores = scores.to(device=dev, dtype=torch.float32).contiguous()
+    if tuple(scores.shape) != (N, lat.vocab):
+        raise ValueError("scores must be [n_lattices * k, vocab]")
+    if inp is not None:
+        inp = _walkers(lat, inp, k, "inp")
+    if values is not None:
+        values = values.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+        if values.shape[0] != lat.total_rows:
+            raise ValueError("values must be row-indexed [total_rows]")
+    if uniforms is None and forced is None:
+        uniforms = torch.rand(N, device=dev)
+    if uniforms is not None:
+        uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous().reshape(N)
+    if forced is not None:
+        forced = forced.to(device=dev, dtype=torch.int64).contiguous().reshape(N)
+    sym = torch.empty(N, dtype=torch.int64, device=dev)
+    nxt = torch.empty(N, dtype=torch.int64, device=dev)
+    logq = torch.empty(N, dtype=torch.float32, device=dev)
+    logz = torch.empty(N, dtype=torch.float32, device=dev)
+    check(lib.nfst_proposal_step(C.byref(lat.c_struct()), _ptr(state), _ptr(inp), _ptr(scores), _ptr(values), int(pad),
+                                 int(bos), int(eos), int(bool(has_to_end)), float(temperature), _ptr(uniforms), _ptr(forced),
+                                 _ptr(sym), _ptr(logq), _ptr(logz), _ptr(nxt), int(k), _stream()), "nfst_proposal_step")
+    return ProposalStep(sym, logq, logz, nxt)
+
+
 def gather_label_scores(lat: LatticeBatch, theta, arc_scores=None) -> torch.Tensor:
     """Per-arc log weights in canonical order (WFSTScorer, scorers.py:1671-1687)."""
     _need_gpu(lat)

@@ -272,3 +272,43 @@ def evaluate_seq(scores: np.ndarray, seqs: np.ndarray, pad: int, bos: int, eos: 
             sel = flat[np.arange(flat.shape[0]), lab]
         sel = sel.reshape(N, T) * (seqs != pad)
     return sel.sum(axis=1)
+
+
+def proposal_step(emission_k: np.ndarray, transition_k: np.ndarray, scores: np.ndarray, inp: np.ndarray,
+                  state: np.ndarray, length: int, max_length: int, pad: int, bos: int, eos: int,
+                  temperature: float = 1.0, beta: Optional[np.ndarray] = None, uniforms: Optional[np.ndarray] = None,
+                  forced: Optional[np.ndarray] = None) -> dict:
+    """One step of Sampler.stateful_sample (samplers.py:243-297) on the lattice side:
+    left_to_right_score (scorers.py:340-366: pad_masking(scores) + mask_out_invalid, identity
+    activation; with beta the gathered beta "logits" of scorers.py:581-593 are added to the scores),
+    / temperature, Categorical(logits) -> sample (inverse CDF over the marks in id order on
+    ``uniforms``) or evaluate ``forced``, log_prob, logsumexp, update_fsa_state (scorers.py:683-690).
+    float64 arithmetic; ``margin`` = distance of u from the nearest CDF boundary."""
+    N, V = scores.shape
+    x = scores.astype(np.float64).copy()
+    x[:, pad] = 0.0  # pad_masking: the pad column's score counts as 0 (scorers.py:182-187)
+    if beta is not None:
+        x = x + beta_logits(transition_k, beta, state).astype(np.float64)
+    x = (x + mask_out_invalid(emission_k, inp, state, length, max_length, pad, bos, eos).astype(np.float64)) / temperature
+    mx = x.max(axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        logz = (mx + np.log(np.exp(x - mx).sum(axis=1, keepdims=True)))[:, 0]
+        p = np.exp(x - logz[:, None])
+    p = np.where(np.isfinite(x), p, 0.0)
+    cdf = np.cumsum(p, axis=1)
+    margin = np.full(N, np.inf)
+    if forced is not None:
+        sym = forced.astype(np.int64)
+    else:
+        sym = np.empty(N, np.int64)
+        for n in range(N):
+            legal = np.nonzero(p[n] > 0)[0]
+            if legal.size == 0:  # no legal mark: the reference's Categorical would raise
+                sym[n], margin[n] = pad, 0.0
+                continue
+            hit = legal[uniforms[n] < cdf[n, legal]]
+            sym[n] = hit[0] if hit.size else legal[-1]
+            margin[n] = np.min(np.abs(cdf[n, legal] - uniforms[n]))
+    logq = x[np.arange(N), sym] - logz
+    nxt = update_fsa_state(transition_k, sym, state)
+    return {"symbol": sym, "logq": logq, "logz": logz, "next_state": nxt, "margin": margin}

@@ -614,3 +614,58 @@ def test_sampling_and_viterbi_with_bf16_scores(dev):
     assert safe.sum() >= K - 2
     assert np.array_equal(s.paths.cpu().numpy()[0][safe], ref["paths"][safe])
     assert np.max(np.abs(s.logq.cpu().numpy()[0][safe] - ref["logq"][safe])) <= 2e-5
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fused_proposal_step(dev, weighted):
+    """nfst_proposal_step against the numpy restatement of one Sampler.stateful_sample step
+    (samplers.py:243-297): symbols and next states bit-exact away from CDF boundaries, log q and
+    logsumexp within 2e-5; forced evaluation; with and without the beta-value gather."""
+    V, K = 96, 24
+    lats = [synth.layered_lattice(400 + i, n_states=60 + 35 * i, avg_degree=6.0, vocab=V, width=5, span=3, weighted=weighted)
+            for i in range(5)]
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    rng = np.random.default_rng(17)
+    N = len(lats) * K
+    # walkers somewhere on their lattice: random reachable states, consistent previous symbols
+    state = np.zeros(N, np.int64); inp = np.full(N, BOS, np.int64)
+    for b, l in enumerate(lats):
+        for k in range(K):
+            a = int(rng.integers(0, l.n_arcs))
+            if k % 6 == 0:      # just after the implicit bos (transition[0, bos] = state 1)
+                state[b * K + k], inp[b * K + k] = int(l.dst[(l.src == 0) & (l.label == BOS)][0]), BOS
+            elif k % 6 == 1:    # finished: in the sink after eos / pad
+                state[b * K + k], inp[b * K + k] = l.n_rows - 1, (EOS if k % 12 == 1 else PAD)
+            else:
+                state[b * K + k], inp[b * K + k] = l.dst[a], l.label[a]
+    scores = rng.normal(0.0, 1.5, size=(N, V)).astype(np.float32)
+    u = rng.random(N).astype(np.float32)
+    values = rng.normal(0.0, 0.5, size=lat.total_rows).astype(np.float32)
+    for temperature, use_values, has_to_end in ((1.0, False, False), (0.7, True, False), (1.3, False, True)):
+        r = ops.proposal_step(lat, torch.from_numpy(state), torch.from_numpy(scores), k=K, inp=torch.from_numpy(inp),
+                              values=torch.from_numpy(values) if use_values else None, pad=PAD, bos=BOS, eos=EOS,
+                              has_to_end=has_to_end, temperature=temperature, uniforms=torch.from_numpy(u))
+        sym, logq, logz, nxt = (x.cpu().numpy() for x in r)
+        for b, l in enumerate(lats):
+            em, tr = l.dense(weighted=weighted)
+            sl = slice(b * K, (b + 1) * K)
+            em_k = np.broadcast_to(em[None], (K,) + em.shape); tr_k = np.broadcast_to(tr[None], (K,) + tr.shape)
+            r0 = int(lat.row_off[b])
+            beta = np.broadcast_to(values[r0:r0 + l.n_rows][None], (K, l.n_rows)) if use_values else None
+            length, max_length = (5, 3) if has_to_end else (2, 300)
+            o = O.proposal_step(em_k, tr_k, scores[sl], inp[sl], state[sl], length, max_length, PAD, BOS, EOS,
+                                temperature=temperature, beta=beta, uniforms=u[sl].astype(np.float64))
+            finite = np.isfinite(o["logz"])  # a forced end (has_to_end) leaves walkers without an eos arc no legal mark
+            assert finite.all() or has_to_end
+            assert np.all(np.isneginf(logz[sl][~finite])) and np.all(np.isneginf(logq[sl][~finite]))
+            assert np.max(np.abs(logz[sl][finite] - o["logz"][finite])) <= 2e-5
+            safe = (o["margin"] > 1e-5) & finite
+            assert safe.sum() > 0.9 * finite.sum()
+            assert np.array_equal(sym[sl][safe], o["symbol"][safe]) and np.array_equal(nxt[sl][safe], o["next_state"][safe])
+            assert np.max(np.abs(logq[sl][safe] - o["logq"][safe])) <= 2e-5
+            # forced evaluation of the oracle's symbols
+            f = ops.proposal_step(lat, torch.from_numpy(state), torch.from_numpy(scores), k=K, inp=torch.from_numpy(inp),
+                                  values=torch.from_numpy(values) if use_values else None, pad=PAD, bos=BOS, eos=EOS,
+                                  has_to_end=has_to_end, temperature=temperature,
+                                  forced=torch.from_numpy(np.concatenate([sym[:b * K], o["symbol"], sym[(b + 1) * K:]])))
+            assert np.max(np.abs(f.logq.cpu().numpy()[sl][finite] - o["logq"][finite])) <= 2e-5
+            assert np.array_equal(f.next_state.cpu().numpy()[sl][finite], o["next_state"][finite])

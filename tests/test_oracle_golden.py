@@ -115,6 +115,33 @@ def test_sampler_traces_are_accepting_paths(golden_dir):
     assert np.array_equal(O.stripping_pad(samples, PAD), d["stripped"])
 
 
+def test_proposal_step_replays_reference_sampler(golden_dir):
+    """The step restatement (oracle.proposal_step), run in forced mode along the reference sampler's
+    own samples with the uniform FSAMaskScorer logits, reproduces the reference's log q and walks
+    every sample into the sink."""
+    d = load(golden_dir, "sampler")
+    K, max_length = int(d["K"]), int(d["max_length"])
+    samples, log_q = d["samples"], d["log_q"]
+    B, _, V = d["emission"].shape
+    em_k, tr_k = O.expand_k(d["emission"], K), O.expand_k(d["transition"], K)
+    N = B * K
+    state = tr_k[np.arange(N), 0, BOS].copy()  # the implicit bos is consumed first (scorers.py:230-231)
+    inp = np.full(N, BOS, np.int64)
+    acc = np.zeros(N)
+    padded = np.concatenate([samples, np.full((N, 1), PAD, np.int64)], axis=1)
+    for t in range(padded.shape[1]):
+        r = O.proposal_step(em_k, tr_k, np.zeros((N, V), np.float32), inp, state, t + 1, max_length, PAD, BOS, EOS,
+                            forced=padded[:, t])
+        assert np.all(np.isfinite(r["logq"]))  # every reference symbol is legal under the restated masks
+        acc += r["logq"]
+        state, inp = r["next_state"], padded[:, t]
+    assert np.max(np.abs(acc - log_q)) < 1e-5
+    sink = d["transition"].shape[1] - 1
+    for n in range(N):  # ended in a state whose only continuation is the pad loop
+        row = em_k[n, state[n]]
+        assert row[PAD] and row.sum() == 1
+
+
 def test_iwae_and_wfst_score(golden_dir):
     d = load(golden_dir, "iwae")
     theta = d["theta"]
