@@ -126,6 +126,69 @@ class LatticeBatch:
         n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lattices)
         return cls.from_arcs(n_rows, arc_off, src, label, dst, lattices[0].vocab, arc_w=w, device=device, **pack_opts)
 
+    @classmethod
+    def concat(cls, batches: Sequence["LatticeBatch"], device=None) -> "LatticeBatch":
+        """One batch from already packed ones, without running the packer again: pack every
+        example once (in a DataLoader worker, or cache it next to the ``.npz``) and build the
+        step's batch by concatenation -- a few tensor copies and offset fix-ups.
+        The parts must agree in vocabulary and in being weighted or not."""
+        batches = list(batches)
+        if not batches:
+            raise ValueError("nothing to concatenate")
+        h0 = batches[0]._h
+        if any(b._h["vocab"] != h0["vocab"] or b._h["weighted"] != h0["weighted"] for b in batches):
+            raise ValueError("batches differ in vocabulary or in being weighted")
+        SLACK = 512  # words of slack at the end of each tile stream (pack.cpp, finish())
+        cpu = [b if b.device.type == "cpu" else b.to("cpu") for b in batches]
+        rows = arcs = fw = bw = fs = bs = 0
+        metas, parts = [], {k: [] for k in cls._FIELDS if k != "meta"}
+        for b in cpu:
+            h, t = b._h, b._t
+            m = b.meta_host.copy()
+            m[:, _lib.META_ROW_OFF] += rows
+            m[:, _lib.META_ARC_OFF] += arcs
+            m[:, _lib.META_FWD_OFF] += fw
+            m[:, _lib.META_BWD_OFF] += bw
+            m[:, _lib.META_FWD_SLOT_OFF] += fs
+            m[:, _lib.META_BWD_SLOT_OFF] += bs
+            metas.append(m)
+            A = h["total_arcs"]
+            parts["row_ptr"].append(t["row_ptr"] + arcs)  # global arc ids
+            for k in ("arc_src", "arc_dst", "arc_label"):
+                parts[k].append(t[k])
+            if h["weighted"]:
+                parts["arc_w"].append(t["arc_w"])
+            parts["arc_sd"].append(t["arc_sd"][:A])
+            parts["arc_l16"].append(t["arc_l16"][:A])
+            parts["fwd_stream"].append(t["fwd_stream"][: h["fwd_words"] - SLACK])
+            parts["bwd_stream"].append(t["bwd_stream"][: h["bwd_words"] - SLACK])
+            for k in ("fwd_perm", "bwd_perm"):  # slot -> global arc id, -1 = empty slot
+                p = t[k]
+                parts[k].append(torch.where(p >= 0, p + arcs, p))
+            rows += h["total_rows"]; arcs += A
+            fw += h["fwd_words"] - SLACK; bw += h["bwd_words"] - SLACK
+            fs += h["fwd_slots"]; bs += h["bwd_slots"]
+        if max(arcs, fw, bw, fs, bs, rows) > 0x7FFFF000:
+            raise _lib.NfstError(-6, "nfst_amd.LatticeBatch.concat", -1)
+        tensors = {"meta": torch.from_numpy(np.ascontiguousarray(np.concatenate(metas)).reshape(-1).astype(np.int32))}
+        for k, v in parts.items():
+            if k == "arc_w" and not h0["weighted"]:
+                tensors[k] = None
+                continue
+            x = torch.cat(v)
+            if k in ("fwd_stream", "bwd_stream"):
+                x = torch.cat([x, torch.zeros(SLACK, dtype=x.dtype)])
+            elif k in ("arc_sd", "arc_l16"):
+                x = torch.cat([x, torch.zeros(8, dtype=x.dtype)])
+            tensors[k] = x.contiguous()
+        header = dict(h0)
+        header.update(n_lattices=sum(b._h["n_lattices"] for b in cpu), max_rows=max(b._h["max_rows"] for b in cpu),
+                      max_tiles=max(b._h["max_tiles"] for b in cpu), total_rows=rows, total_arcs=arcs,
+                      total_dp_arcs=sum(b._h["total_dp_arcs"] for b in cpu), fwd_words=fw + SLACK, bwd_words=bw + SLACK,
+                      fwd_slots=fs, bwd_slots=bs)
+        out = cls(header, tensors)
+        return out.to(device) if device is not None else out
+
     # ---------------------------------------------------------------- placement
     def to(self, device) -> "LatticeBatch":
         device = torch.device(device)

@@ -159,3 +159,22 @@ def test_synth_is_deterministic():
     # the checksum pins the generator across machines / numpy builds
     h = int((a.src.astype(np.int64) * 31 + a.label * 17 + a.dst).sum() % (2 ** 31))
     assert h == int((b.src.astype(np.int64) * 31 + b.label * 17 + b.dst).sum() % (2 ** 31))
+
+
+def test_concat_of_packed_parts_equals_packing_the_batch():
+    """Pack once per example, batch by concatenation: the result is bit-identical to
+    packing the whole batch, for plain and weighted lattices and for parts of several lattices."""
+    import torch
+    for weighted in (False, True):
+        lats = [synth.layered_lattice(70 + i, n_states=40 + 31 * i, avg_degree=5.0, vocab=64, width=1 + i % 4, span=3, weighted=weighted)
+                for i in range(6)]
+        whole = LatticeBatch.from_synth(lats)
+        for groups in ([[l] for l in lats], [lats[:2], lats[2:3], lats[3:]]):
+            cat = LatticeBatch.concat([LatticeBatch.from_synth(g) for g in groups])
+            for k in LatticeBatch._FIELDS:
+                a, b = getattr(whole, k), getattr(cat, k)
+                assert (a is None and b is None) or (a.dtype == b.dtype and torch.equal(a, b)), k
+            assert whole._h == cat._h
+    with pytest.raises(ValueError):
+        LatticeBatch.concat([LatticeBatch.from_synth(lats[:1]),
+                             LatticeBatch.from_synth([synth.layered_lattice(1, n_states=30, avg_degree=4.0, vocab=32, width=2, span=2)])])
