@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define NFST_ABI_VERSION 2
+#define NFST_ABI_VERSION 3
 
 /* error codes */
 #define NFST_OK 0
@@ -191,6 +191,12 @@ typedef struct nfst_scores {
   const float *theta;
   int64_t theta_stride;
   const float *arc_scores;
+  float *slot_ws;          /* workspace of fwd_slots + bwd_slots floats, required by nfst_backward and
+                              nfst_forward_backward when the batch is weighted or arc_scores is given: the launch
+                              first writes the per-arc extras in tile-slot order into it, so that the sweeps
+                              stream them like the arc records instead of gathering them arc by arc */
+  int64_t slot_ws_ready;   /* non-zero: slot_ws already holds the extras of exactly this batch and arc_scores
+                              (e.g. a weighted batch without arc_scores launched before): skip refilling it */
 } nfst_scores;
 
 /*

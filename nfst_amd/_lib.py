@@ -45,7 +45,8 @@ class Batch(C.Structure):
 
 
 class Scores(C.Structure):
-    _fields_ = [("theta", C.c_void_p), ("theta_stride", C.c_int64), ("arc_scores", C.c_void_p)]
+    _fields_ = [("theta", C.c_void_p), ("theta_stride", C.c_int64), ("arc_scores", C.c_void_p), ("slot_ws", C.c_void_p),
+                ("slot_ws_ready", C.c_int64)]
 
 
 class PackOpts(C.Structure):
@@ -92,7 +93,7 @@ def _load():
 
 
 lib, EXPORTS = _load()
-if lib.nfst_abi_version() != 2:
+if lib.nfst_abi_version() != 3:
     raise ImportError("libnfst_hip.so ABI version mismatch; rebuild with `python -m nfst_amd.build --force`")
 
 

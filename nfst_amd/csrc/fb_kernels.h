@@ -2,6 +2,20 @@
 // Part of the single translation unit kernels.hip (device code in an anonymous namespace).
 #pragma once
 
+// Per-arc extras (table weights + caller scores, canonical arc order) -> tile-slot order of the
+// forward program, then of the backward program; empty slots and carry records get 0.
+__global__ __launch_bounds__(256) void k_slot_extras(nfst_batch lat, nfst_scores sc, int64_t first, int64_t n) {
+  const int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int a = i < lat.fwd_slots ? lat.fwd_perm[i] : lat.bwd_perm[i - lat.fwd_slots];
+  float x = 0.0f;
+  if (a >= 0) {
+    if (lat.weighted) x += lat.arc_w[a];
+    if (sc.arc_scores) x += sc.arc_scores[a];
+  }
+  sc.slot_ws[i] = x;
+}
+
 // ------------------------------------------------------------------ LDS layout
 // [alpha: rows2 float2][beta: rows2 float2][theta: v2 float2 (V labels + null + unit)]
 // [label histogram: v4 float][per sweep: R decoded tiles, kRawSlots raw tiles][4 flag words per sweep]  (16-B aligned)
@@ -44,12 +58,14 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   uint32_t *raw = ring + (size_t)R * kSlotWords;
   // NT = 512: the workgroup has the CU to itself: wave 2 loads for the decoder (deep staging
   // ring); NT = 256: two workgroups per CU, the decoder loads for itself
+  // slot-ordered per-arc extras of the backward program (only read by the kernels with EXTRA)
+  const int32_t *bwd_extras = (const int32_t *)(sc.slot_ws + lat.fwd_slots + m.bwd_slot_off);
   constexpr bool kSelf = NT != 512;
   constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
   if (kSelf) {
-    if (wv == 1) self_start<EXTRA, kAhead>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, raw, lane);
+    if (wv == 1) self_start<EXTRA, kAhead>(m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_extras, m.bwd_tiles, raw, lane);
   } else if (wv == 2) {
-    loader_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, raw, RS, lane);
+    loader_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_extras, m.bwd_tiles, raw, RS, lane);
   }
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
@@ -61,7 +77,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   }
   __syncthreads();
   if (wv < (kSelf ? 2 : 3))
-    run_sweep<EXTRA, kSelf, kAhead>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off,
+    run_sweep<EXTRA, kSelf, kAhead>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off, bwd_extras,
               m.bwd_tiles, ring, R, flags, beta, th, ex, lane);
   __syncthreads();
   if (tid == 0) {
@@ -116,7 +132,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // the sweep waves share theirs only with waves that sleep at the barrier)
   const bool bwd_side = (wv & 1) == 0;
   const uint32_t *my_prog = bwd_side ? lat.bwd_stream + m.bwd_off : lat.fwd_stream + m.fwd_off;
-  const int32_t *my_perm = bwd_side ? lat.bwd_perm + m.bwd_slot_off : lat.fwd_perm + m.fwd_slot_off;
+  // slot-ordered per-arc extras of this sweep (only read by the kernels with EXTRA)
+  const int32_t *my_perm = (const int32_t *)(sc.slot_ws + (bwd_side ? lat.fwd_slots + m.bwd_slot_off : m.fwd_slot_off));
   const int my_tiles = bwd_side ? m.bwd_tiles : m.fwd_tiles;
   const int my_u = bwd_side ? m.bwd_u : m.fwd_u;
   const bool my_wide = (bwd_side ? m.bwd_wide : m.fwd_wide) != 0;

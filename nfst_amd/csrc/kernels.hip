@@ -125,6 +125,12 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   const LdsPlan plan(lat->max_rows, lat->vocab);
   RingCfg cfg;
   if (!ring_config(plan, false, extra, lat->n_lattices <= cu_count(), &cfg)) return NFST_ERR_LIMIT;
+  if (extra) {  // slot-ordered extras of the backward program
+    if (!scores->slot_ws) return NFST_ERR_ARG;
+    if (lat->bwd_slots > 0 && !scores->slot_ws_ready)
+      hipLaunchKernelGGL(k_slot_extras, dim3((unsigned)((lat->bwd_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *lat,
+                         *scores, (int64_t)lat->fwd_slots, (int64_t)(lat->fwd_slots + lat->bwd_slots));
+  }
   const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.bwd_bytes(R, RS, extra);
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
@@ -154,6 +160,13 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   const int cus = cu_count();
   RingCfg cfg;
   if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
+  if (extra) {  // slot-ordered extras of both programs
+    if (!scores->slot_ws) return NFST_ERR_ARG;
+    const int64_t n = lat->fwd_slots + lat->bwd_slots;
+    if (n > 0 && !scores->slot_ws_ready)
+      hipLaunchKernelGGL(k_slot_extras, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *lat, *scores,
+                         (int64_t)0, n);
+  }
   const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \

@@ -211,8 +211,8 @@ struct DmaOps {
   static constexpr int value = F == 8 ? (EXTRA ? 2 : 1) : (F == 2 ? 3 : 2) + (EXTRA ? (F == 2 ? 2 : 1) : 0);
 };
 
-// raw staging slot: [64 control words][64 U records]([64 U canonical arc ids]); compact tiles:
-// [64 x (control word, 3 record words)]([256 canonical arc ids])
+// raw staging slot: [64 control words][64 U records]([64 U slot-ordered extra log weights]); compact
+// tiles: [64 x (control word, 3 record words)]([256 extras]).  `perm` is that slot-ordered stream.
 template <int F, bool EXTRA>
 __device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *perm, int tile, uint32_t slot_addr, int lane) {
   constexpr int U = fmt_u(F);
@@ -323,7 +323,7 @@ struct RawRegs {
   uint32_t ctl;
   uint32_t opoff[U];
   uint32_t lab8[U];
-  int32_t pm[EXTRA ? U : 1];
+  int32_t pm[EXTRA ? U : 1];  // bits of the slots' extra log weights (kernels with per-arc extras)
 };
 template <int F, bool EXTRA>
 __device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<fmt_u(F), EXTRA> &w) {
@@ -398,7 +398,7 @@ template <int F, bool EXTRA, bool SELF, int AHEAD>
 __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, int RS, const int *rland,
                                              const uint32_t *g, const int32_t *perm,
                                              uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
-                                             const float2 *th_, const Extra ex, int lane) {
+                                             const float2 *th_, const Extra /*ex: extras arrive with the tiles*/, int lane) {
   if (n_tiles <= 0) {
     if (SELF) vm_wait<0>();
     return;
@@ -469,15 +469,13 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     else if (U == 2) *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
     else *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
     if (EXTRA) {
-      // per-arc extras: plain loads, waited for in place (lattices with per-arc extras
-      // decode at about one memory latency per tile)
+      // per-arc extras (table weights + caller scores) arrive in slot order with the tile
+      // (k_slot_extras wrote them before the sweeps): no gather here
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        if (cur.pm[j] >= 0) {
-          const ME x = exp_split(ex.at(cur.pm[j]));
-          tw[j].x *= x.m;
-          tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
-        }
+        const ME x = exp_split(__int_as_float(cur.pm[j]));
+        tw[j].x *= x.m;
+        tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
       }
     }
     if (U == 4) {

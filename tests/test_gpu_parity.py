@@ -669,3 +669,28 @@ def test_fused_proposal_step(dev, weighted):
                                   forced=torch.from_numpy(np.concatenate([sym[:b * K], o["symbol"], sym[(b + 1) * K:]])))
             assert np.max(np.abs(f.logq.cpu().numpy()[sl][finite] - o["logq"][finite])) <= 2e-5
             assert np.array_equal(f.next_state.cpu().numpy()[sl][finite], o["next_state"][finite])
+
+
+def test_slot_ordered_extras_workspace_sequences(dev):
+    """Per-arc extras travel to the sweeps through a per-batch workspace in tile-slot order, refilled
+    by every launch unless only the (static) table weights are in play.  Any order of backward /
+    forward_backward launches, with and without caller scores, must give the oracle's numbers."""
+    lats = [synth.layered_lattice(s, n_states=120 + 40 * s, avg_degree=6.0, vocab=48, width=6, span=3, weighted=True) for s in range(3)]
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    theta = synth.label_scores(2, 48)
+    rng = np.random.default_rng(5)
+    asc1 = rng.normal(0.0, 0.3, size=lat.total_arcs).astype(np.float32)
+    asc2 = rng.normal(0.0, 0.3, size=lat.total_arcs).astype(np.float32)
+    def want(asc):
+        out = []
+        for b, l in enumerate(lats):
+            a0 = int(lat.arc_off[b])
+            out.append(oracle_fb(l, theta, None if asc is None else asc[a0:a0 + l.n_arcs])[0]["logZ"])
+        return np.array(out)
+    th = torch.from_numpy(theta)
+    plan = [("bwd", None), ("fb", None), ("bwd", None), ("fb", asc1), ("bwd", None), ("bwd", asc2), ("fb", None), ("fb", asc2),
+            ("fb", None), ("bwd", asc1), ("fb", None)]
+    for op, asc in plan:
+        t = None if asc is None else torch.from_numpy(asc)
+        r = ops.forward_backward(lat, th, arc_scores=t) if op == "fb" else ops.backward(lat, th, arc_scores=t)
+        assert np.max(np.abs(r.logz64.cpu().numpy() - want(asc))) <= TOL, (op, asc is None)
