@@ -86,7 +86,8 @@ extern "C" {
 #define NFST_META_N_REACH 9    /* states reachable from 0 */
 #define NFST_META_DEPTH 10     /* longest path, in arcs */
 #define NFST_META_N_DP 11      /* non-self-loop arcs */
-#define NFST_META_FWD_U 12     /* arc slots per lane of the alpha program: 1, 2 or 4 */
+#define NFST_META_FWD_U 12     /* alpha program format: bits [0:8) 1, 2 or 4 arc slots per lane in 32-bit records,
+                                  or 8 = four 24-bit records per lane; bit 8 = wide groups (up to 64 lanes) */
 #define NFST_META_BWD_U 13
 #define NFST_META_FWD_SLOT_OFF 14 /* first slot of this lattice in fwd_perm */
 #define NFST_META_BWD_SLOT_OFF 15
