@@ -89,6 +89,21 @@ def cpu_baseline(lats, theta, budget_s=12.0):
     return out
 
 
+def measured_copy_gbs(dev, mib: int = 1024, reps: int = 10) -> float:
+    """What a plain device-to-device copy of 1 GiB reaches on this card (read + write bytes per
+    second), the figure SURVEY.md section 8d wants beside the 8 TB/s nameplate peak."""
+    src = torch.empty(mib << 20, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * src.numel() * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,6 +290,7 @@ def main():
                          "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
                          "kernel": "k_forward_backward", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
         }
+        out["roofline"]["hbm_copy_measured"] = measured_copy_gbs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lats, theta_np, args.cpu_budget)
         print(json.dumps(out))

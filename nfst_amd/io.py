@@ -36,3 +36,42 @@ def pad_sequence(sequences: Sequence[np.ndarray], padding_value=0) -> np.ndarray
 def collate(batch: Sequence[Tuple[np.ndarray, ...]], pad: int):
     """Six padded arrays, like the reference's collate (dataset_reader.py:175-186)."""
     return tuple(pad_sequence([b[i] for b in batch], padding_value=pad) for i in range(6))
+
+
+def packed_sidecar(npz_fname: str, which: str = "num") -> str:
+    return npz_fname[: -len(".npz")] + f".{which}.nfst.npz" if npz_fname.endswith(".npz") else npz_fname + f".{which}.nfst.npz"
+
+
+def load_packed(npz_fname: str, which: str = "num", cache: bool = True):
+    """The ``num`` (or ``denom``) lattice of one example as a packed one-lattice batch.  The
+    packer runs the first time an example is seen; its output is kept in a sidecar file beside
+    the ``.npz`` (``cache=True``) and only read back afterwards -- what a DataLoader worker
+    does instead of shipping the 5 MB dense tables (``FSADataset.__getitem__``,
+    dataset_reader.py:30-40).  A stale sidecar (older than the ``.npz``, or packed for another
+    ABI version) is rebuilt."""
+    import os
+
+    from .lattice import LatticeBatch
+
+    side = packed_sidecar(npz_fname, which)
+    if cache and os.path.exists(side) and os.path.getmtime(side) >= os.path.getmtime(npz_fname):
+        try:
+            return LatticeBatch.load(side)
+        except ValueError:
+            pass
+    with np.load(npz_fname, allow_pickle=False) as l:
+        em, tr = l[f"{which}_emission"], l[f"{which}_transition"]
+    lat = LatticeBatch.from_dense(em[None], tr[None])
+    if cache:
+        tmp = side + f".{os.getpid()}.tmp.npz"
+        lat.save(tmp)
+        os.replace(tmp, side)  # workers may race for the same example
+    return lat
+
+
+def collate_packed(examples, device=None):
+    """Batch of packed examples -> one LatticeBatch (``collate``, dataset_reader.py:175-186,
+    without the pad-id padding rows: every lattice keeps its own row count)."""
+    from .lattice import LatticeBatch
+
+    return LatticeBatch.concat(list(examples), device=device)

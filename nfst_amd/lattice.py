@@ -37,6 +37,8 @@ class LatticeBatch:
 
     _FIELDS = ("meta", "row_ptr", "arc_src", "arc_dst", "arc_label", "arc_w", "fwd_stream", "bwd_stream",
                "fwd_perm", "bwd_perm", "arc_sd", "arc_l16")
+    _HEADER = ("n_lattices", "vocab", "max_rows", "max_tiles", "weighted", "reserved0", "total_rows", "total_arcs",
+               "total_dp_arcs", "fwd_words", "bwd_words", "fwd_slots", "bwd_slots")
 
     def __init__(self, header: dict, tensors: dict):
         self._h = dict(header)
@@ -69,9 +71,7 @@ class LatticeBatch:
                 "arc_sd": _view(v.arc_sd, v.total_arcs + 8, C.c_int32, np.int32),
                 "arc_l16": _view(v.arc_l16, v.total_arcs + 8, C.c_int16, np.int16),
             }
-            header = {k: int(getattr(v, k)) for k in ("n_lattices", "vocab", "max_rows", "max_tiles", "weighted", "reserved0",
-                                                      "total_rows", "total_arcs", "total_dp_arcs", "fwd_words",
-                                                      "bwd_words", "fwd_slots", "bwd_slots")}
+            header = {k: int(getattr(v, k)) for k in cls._HEADER}
         finally:
             lib.nfst_packed_free(handle)
         tensors = {k: (None if a is None else torch.from_numpy(a)) for k, a in arrs.items()}
@@ -186,6 +186,39 @@ class LatticeBatch:
                       max_tiles=max(b._h["max_tiles"] for b in cpu), total_rows=rows, total_arcs=arcs,
                       total_dp_arcs=sum(b._h["total_dp_arcs"] for b in cpu), fwd_words=fw + SLACK, bwd_words=bw + SLACK,
                       fwd_slots=fs, bwd_slots=bs)
+        out = cls(header, tensors)
+        return out.to(device) if device is not None else out
+
+    # ---------------------------------------------------------------- sidecar files
+    _MAGIC = "nfst-packed"
+
+    def save(self, fname: str) -> None:
+        """Write the packed arrays next to the example's ``.npz`` (an uncompressed ``.npz`` of
+        plain arrays): the packer then runs once per example, offline or in a DataLoader worker,
+        and a step's batch is ``concat`` of loaded sidecars."""
+        arrs = {k: v.detach().cpu().numpy() for k, v in self._t.items() if v is not None}
+        header = np.array([self._h[k] for k in self._HEADER], dtype=np.int64)
+        np.savez(fname, magic=np.array(self._MAGIC), abi=np.int64(lib.nfst_abi_version()), header=header, **arrs)
+
+    @classmethod
+    def load(cls, fname: str, device=None) -> "LatticeBatch":
+        with np.load(fname, allow_pickle=False) as l:
+            if "magic" not in l.files or str(l["magic"]) != cls._MAGIC:
+                raise ValueError(f"{fname} is not a packed lattice file")
+            if int(l["abi"]) != lib.nfst_abi_version():
+                raise ValueError(f"{fname} was packed for ABI {int(l['abi'])}, the library is ABI "
+                                 f"{lib.nfst_abi_version()}: pack it again")
+            header = {k: int(v) for k, v in zip(cls._HEADER, l["header"])}
+            tensors = {k: (torch.from_numpy(l[k]) if k in l.files else None) for k in cls._FIELDS}
+        B, A = header["n_lattices"], header["total_arcs"]
+        want = {"meta": B * _lib.META_WORDS, "row_ptr": header["total_rows"] + B, "arc_src": A, "arc_dst": A,
+                "arc_label": A, "fwd_stream": header["fwd_words"], "bwd_stream": header["bwd_words"],
+                "fwd_perm": header["fwd_slots"], "bwd_perm": header["bwd_slots"], "arc_sd": A + 8, "arc_l16": A + 8}
+        if header["weighted"]:
+            want["arc_w"] = A
+        for k, n in want.items():
+            if tensors[k] is None or tensors[k].numel() != n:
+                raise ValueError(f"{fname}: array {k} does not match the header")
         out = cls(header, tensors)
         return out.to(device) if device is not None else out
 

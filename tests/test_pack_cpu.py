@@ -178,3 +178,43 @@ def test_concat_of_packed_parts_equals_packing_the_batch():
     with pytest.raises(ValueError):
         LatticeBatch.concat([LatticeBatch.from_synth(lats[:1]),
                              LatticeBatch.from_synth([synth.layered_lattice(1, n_states=30, avg_degree=4.0, vocab=32, width=2, span=2)])])
+
+
+def test_packed_sidecar_round_trip(tmp_path):
+    """8f-1: an example's .npz is packed once, kept beside it, and a batch is the concatenation of
+    loaded sidecars -- bit-identical to packing the collated dense tables."""
+    from nfst_amd import io
+    V, pad = 24, 0
+    lats = [synth.layered_lattice(90 + i, n_states=18 + 9 * i, avg_degree=3.0, vocab=V, width=2, span=2) for i in range(3)]
+    dense = [l.dense() for l in lats]
+    names = []
+    for i, (em, tr) in enumerate(dense):
+        f = str(tmp_path / f"ex{i}.npz")
+        io.save_fsa_npz(f, (em, tr), (em, tr), np.arange(3), np.arange(4))
+        names.append(f)
+    first = [io.load_packed(f) for f in names]
+    assert all(os.path.exists(io.packed_sidecar(f)) for f in names)
+    again = [io.load_packed(f) for f in names]  # from the sidecars
+    for a, b in zip(first, again):
+        assert a._h == b._h
+        for k in LatticeBatch._FIELDS:
+            x, y = getattr(a, k), getattr(b, k)
+            assert (x is None and y is None) or (x.dtype == y.dtype and torch.equal(x, y)), k
+    batch = io.collate_packed(again)
+    col = io.collate([io.load_fsa_from_npz(f) for f in names], pad)
+    whole = LatticeBatch.from_dense(col[0], col[1])
+    assert np.array_equal(batch.n_arcs, whole.n_arcs)
+    for k in ("arc_src", "arc_dst", "arc_label", "fwd_stream", "bwd_stream", "fwd_perm", "bwd_perm"):
+        assert torch.equal(getattr(batch, k), getattr(whole, k)), k
+    # a file that is not a sidecar, and a sidecar of another ABI version, are refused
+    with pytest.raises(ValueError):
+        LatticeBatch.load(names[0])
+    side = io.packed_sidecar(names[0])
+    with np.load(side) as l:
+        d = {k: l[k] for k in l.files}
+    d["abi"] = np.int64(1)
+    np.savez(side, **d)
+    with pytest.raises(ValueError, match="ABI"):
+        LatticeBatch.load(side)
+    os.utime(side, (os.path.getmtime(names[0]) + 10,) * 2)
+    assert io.load_packed(names[0])._h == first[0]._h  # rebuilt
