@@ -14,6 +14,7 @@ What is pinned (reference file:line):
   beta_*.npz     FSAGRUScorer.compute_beta_per_sample / compute_beta_parallel
                  (scorers.py:692-751, 753-856) with Wh = 0, i.e. arc weight
                  exp(theta[label]);  includes the parallel-arc quirk fixture.
+  beta_neural.npz  the same two functions with Wh != 0 (Tree-LSTM-style messages).
   gather.npz     set_masks/set_k (877-918), update_fsa_state (683-690),
                  mask_out_invalid (1037-1054 on top of 314-338) on a collated,
                  pad-padded batch (dataset_reader.py:175-186).
@@ -175,6 +176,41 @@ def make_beta():
     save("beta_parallel_arc_quirk.npz", theta=theta, beta_per_sample=b_serial, beta_parallel=b_par, **sc._probe_weights, **lattice_arrays(lat))
 
 
+def make_beta_neural():
+    """Wh != 0: the Tree-LSTM-style messages of compute_beta_per_sample (scorers.py:692-751), and
+    compute_beta_parallel (753-856) on the same lattices (none has parallel arcs between a state pair
+    except where noted, so both agree)."""
+    cases = {
+        "neural_layered12_h8": (synth.layered_lattice(31, n_states=12, avg_degree=3.0, vocab=29, width=3, span=2), 8),
+        "neural_layered40_h16": (synth.layered_lattice(32, n_states=40, avg_degree=4.0, vocab=29, width=4, span=3), 16),
+        "neural_layered90_h64": (synth.layered_lattice(33, n_states=90, avg_degree=5.0, vocab=29, width=5, span=3), 64),
+        "neural_edit_h8": (synth.edit_lattice([10, 11, 12], [20, 21, 22, 23], vocab=29, seed=6), 8),
+        "neural_parallel_arcs_h8": (synth.layered_lattice(34, n_states=20, avg_degree=4.0, vocab=29, width=2, span=2), 8),
+    }
+    out = {}
+    for name, (lat, H) in cases.items():
+        torch.manual_seed(len(name) + H)
+        sc = FSAGRUScorer(hid_dim=H, vocab_size=lat.vocab, pad=PAD, bos=BOS, eos=EOS, use_beta=True, max_length=64)
+        sc.eval()
+        with torch.no_grad():
+            sc.beta_bias.copy_(0.3 * torch.randn(H))
+            sc.Wh.mul_(2.0)  # make the state term matter
+        em, tr = lat.dense()
+        tr_t = torch.from_numpy(tr)
+        with torch.no_grad():
+            b_serial = sc.compute_beta_per_sample(tr_t).numpy().astype(np.float32)
+            sc.set_masks(emission=torch.from_numpy(em)[None], transition=tr_t[None])
+            sc.set_k(1)
+            b_par = sc.compute_beta().numpy().astype(np.float32)[0]
+        out.update({f"{name}_{k}": v for k, v in dict(
+            beta_per_sample=b_serial, beta_parallel=b_par,
+            emb=sc.embeddings.weight.detach().numpy().astype(np.float32), Wx=sc.Wx.detach().numpy().astype(np.float32),
+            Wh=sc.Wh.detach().numpy().astype(np.float32), W=sc.W.detach().numpy().astype(np.float32),
+            bias=sc.beta_bias.detach().numpy().astype(np.float32), n_rows=np.int64(lat.n_rows),
+            src=lat.src, label=lat.label, dst=lat.dst, transition=tr).items()})
+    save("beta_neural.npz", **out)
+
+
 def make_gather():
     V = 24
     lats = [
@@ -326,7 +362,7 @@ def make_evalseq():
 
 
 if __name__ == "__main__":
-    make_beta()
-    make_gather()
-    make_sampler_and_iwae()
-    make_evalseq()
+    only = set(sys.argv[1:])  # e.g. `make_golden.py make_beta_neural`; nothing = all
+    for fn in (make_beta, make_beta_neural, make_gather, make_sampler_and_iwae, make_evalseq):
+        if not only or fn.__name__ in only:
+            fn()

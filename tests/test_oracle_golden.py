@@ -194,3 +194,27 @@ def test_viterbi_and_sampling_consistency():
     # empirical arc frequencies approach the posteriors
     cnt = np.bincount(s["arcs"][s["arcs"] >= 0], minlength=lat.n_arcs) / K
     assert np.max(np.abs(cnt - r["posterior"])) < 0.05
+
+
+NEURAL = ["neural_layered12_h8", "neural_layered40_h16", "neural_layered90_h64", "neural_edit_h8", "neural_parallel_arcs_h8"]
+
+
+def neural_case(golden_dir, name):
+    with np.load(os.path.join(golden_dir, "beta_neural.npz")) as g:
+        return {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+
+
+@pytest.mark.parametrize("name", NEURAL)
+def test_beta_neural_matches_reference(golden_dir, name):
+    """Wh != 0: the float64 restatement equals compute_beta_per_sample's float32
+    probabilities, and compute_beta_parallel's through the dense-frontier restatement."""
+    c = neural_case(golden_dir, name)
+    logb, bhat = O.beta_neural(int(c["n_rows"]), c["src"], c["label"], c["dst"], c["emb"], c["Wx"], c["Wh"], c["W"], c["bias"])
+    ref = c["beta_per_sample"].astype(np.float64)
+    assert np.all(ref[1:] > 0)
+    np.testing.assert_allclose(np.exp(logb), ref, rtol=2e-5, atol=0)
+    assert np.all(np.abs(bhat) <= 1.0 + 1e-12) and np.all(bhat[-1] == 0)
+    par, _ = O.beta_dense_frontier(c["transition"], c["emb"], c["Wx"], c["Wh"], c["W"], c["bias"])
+    np.testing.assert_allclose(par, c["beta_parallel"], rtol=2e-5, atol=1e-30)
+    if name == "neural_edit_h8":  # no state pair with two labels: parallel == per-sample
+        np.testing.assert_allclose(c["beta_parallel"], ref, rtol=2e-5)
