@@ -296,6 +296,22 @@ int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_
                        const float *uniforms, const int64_t *forced, int64_t *symbol, float *logq, float *logz,
                        int64_t *next_state, int32_t k, void *stream);
 
+/*
+ * Neuralised beta: FSAGRUScorer.compute_beta_per_sample with Wh != 0
+ * (modules/scorers.py:692-751; compute_beta_parallel, 753-856, is the same
+ * recurrence).  For every arc (s, l, s') with s' != s
+ *     t   = tanh(label_x[l] + Wh . beta_hat(s')),  label_x[l] = Wx . e(l) + bias
+ *     msg = exp(w . t (+ arc_w)) * beta(s')
+ *     beta(s) = sum msg,  beta_hat(s) = sum (msg / beta(s)) t;  beta(sink) = 1, beta_hat(sink) = 0.
+ * label_x: device float32 [vocab, hid]; wh_t: Wh transposed, [hid (in), hid (out)]
+ * row-major; w: [hid]; hid <= 512.  Outputs: log_beta [total_rows] (natural log;
+ * the reference returns exp of it), beta_hat [total_rows, hid].  ws: device
+ * workspace of nfst_neural_ws_floats() floats, contents irrelevant.
+ */
+int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid);
+int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w,
+                         int32_t hid, float *log_beta, float *beta_hat, float *ws, void *stream);
+
 /* out[a] = theta[(theta_stride * b) + label[a]] (+ arc_w[a]) (+ arc_scores[a]) */
 int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, float *out,
                              void *stream);

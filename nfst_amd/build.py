@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "pack.cpp"), os.path.join(HERE, "csrc", "kernels.hip")]
 HDR = os.path.join(ROOT, "include", "nfst_hip.h")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("semiring.h", "tile_pipeline.h", "fb_kernels.h", "path_kernels.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("semiring.h", "tile_pipeline.h", "fb_kernels.h", "path_kernels.h", "neural_kernels.h")]
 OUT = os.path.join(HERE, "lib", "libnfst_hip.so")
 
 

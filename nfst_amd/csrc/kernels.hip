@@ -20,6 +20,7 @@ namespace {
 #include "tile_pipeline.h"
 #include "fb_kernels.h"
 #include "path_kernels.h"
+#include "neural_kernels.h"
 
 // ------------------------------------------------------------------ host helpers
 int check_batch(const nfst_batch *lat) {
@@ -282,6 +283,32 @@ int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_
   hipLaunchKernelGGL(k_proposal_step, dim3((unsigned)((n + kStepWaves - 1) / kStepWaves)), dim3(64 * kStepWaves), (size_t)lds,
                      (hipStream_t)stream, *lat, state, inp, scores, values, (int)pad, (int)bos, (int)eos, (int)has_to_end,
                      temperature, uniforms, forced, symbol, logq, logz, next_state, (int)k, n);
+  return hip_status(hipGetLastError());
+}
+
+int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid) {
+  if (!lat || hid <= 0) return NFST_ERR_ARG;
+  return 2 * (int64_t)lat->n_lattices * lat->max_rows * hid;
+}
+
+int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w, int32_t hid,
+                         float *log_beta, float *beta_hat, float *ws, void *stream) {
+  int rc = check_batch(lat);
+  if (rc) return rc;
+  if (!label_x || !wh_t || !w || !log_beta || !beta_hat || !ws || hid <= 0) return NFST_ERR_ARG;
+  if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
+  const int64_t lds = NeuLds(lat->max_rows, hid).bytes();
+#define NFST_LAUNCH_NEU(HC)                                                                                   \
+  do {                                                                                                        \
+    if ((rc = set_lds(k_backward_neural<HC>, lds))) return rc;                                                \
+    hipLaunchKernelGGL(k_backward_neural<HC>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,          \
+                       (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, log_beta, beta_hat, ws);        \
+  } while (0)
+  if (hid <= 64) NFST_LAUNCH_NEU(1);
+  else if (hid <= 128) NFST_LAUNCH_NEU(2);
+  else if (hid <= 256) NFST_LAUNCH_NEU(4);
+  else NFST_LAUNCH_NEU(8);
+#undef NFST_LAUNCH_NEU
   return hip_status(hipGetLastError());
 }
 

@@ -329,6 +329,36 @@ def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, 
     return ProposalStep(sym, logq, logz, nxt)
 
 
+class NeuralBeta(NamedTuple):
+    log_beta: torch.Tensor   # [total_rows] natural log of the reference's beta
+    beta_hat: torch.Tensor   # [total_rows, H]
+
+
+def backward_neural(lat: LatticeBatch, emb: torch.Tensor, Wx: torch.Tensor, Wh: torch.Tensor, W: torch.Tensor,
+                    bias: torch.Tensor) -> NeuralBeta:
+    """``FSAGRUScorer.compute_beta_per_sample`` / ``compute_beta_parallel`` with their Tree-LSTM-style
+    messages (scorers.py:692-751, 753-856), parameters named as there: ``emb`` [V, H] mark embeddings,
+    ``Wx``, ``Wh`` [H, H], ``W`` [1, H] or [H], ``bias`` [H].  The per-label part ``Wx e(l) + bias`` is
+    one [V, H] x [H, H] product made here (a plain library GEMM); everything that depends on the
+    lattice runs in the kernel."""
+    _need_gpu(lat)
+    f32 = dict(device=lat.device, dtype=torch.float32)
+    emb, Wx, Wh, bias = emb.to(**f32), Wx.to(**f32), Wh.to(**f32), bias.to(**f32)
+    w = W.to(**f32).reshape(-1).contiguous()
+    H = w.shape[0]
+    if emb.shape != (lat.vocab, H) or Wx.shape != (H, H) or Wh.shape != (H, H) or bias.shape != (H,):
+        raise ValueError("emb must be [V, H], Wx and Wh [H, H], W [H] and bias [H]")
+    label_x = torch.addmm(bias, emb, Wx.t()).contiguous()
+    wh_t = Wh.t().contiguous()
+    s = lat.c_struct()
+    ws = torch.empty(int(lib.nfst_neural_ws_floats(C.byref(s), H)), **f32)
+    log_beta = torch.empty(lat.total_rows, **f32)
+    beta_hat = torch.empty(lat.total_rows, H, **f32)
+    check(lib.nfst_backward_neural(C.byref(s), label_x.data_ptr(), wh_t.data_ptr(), w.data_ptr(), H, log_beta.data_ptr(),
+                                   beta_hat.data_ptr(), ws.data_ptr(), _stream()), "nfst_backward_neural")
+    return NeuralBeta(log_beta, beta_hat)
+
+
 def gather_label_scores(lat: LatticeBatch, theta, arc_scores=None) -> torch.Tensor:
     """Per-arc log weights in canonical order (WFSTScorer, scorers.py:1671-1687)."""
     _need_gpu(lat)

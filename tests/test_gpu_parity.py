@@ -694,3 +694,82 @@ def test_slot_ordered_extras_workspace_sequences(dev):
         t = None if asc is None else torch.from_numpy(asc)
         r = ops.forward_backward(lat, th, arc_scores=t) if op == "fb" else ops.backward(lat, th, arc_scores=t)
         assert np.max(np.abs(r.logz64.cpu().numpy() - want(asc))) <= TOL, (op, asc is None)
+
+
+# ----------------------------------------------------------------------------- neuralised beta
+NEURAL = ["neural_layered12_h8", "neural_layered40_h16", "neural_layered90_h64", "neural_edit_h8", "neural_parallel_arcs_h8"]
+
+
+def _neural_params(seed, V, H, scale=1.0):
+    g = np.random.default_rng(seed)
+    lim = np.sqrt(6.0 / (2 * H))  # xavier_uniform like scorers.py:958-967
+    return dict(emb=g.standard_normal((V, H)).astype(np.float32), Wx=g.uniform(-lim, lim, (H, H)).astype(np.float32),
+                Wh=(scale * g.uniform(-lim, lim, (H, H))).astype(np.float32),
+                W=g.uniform(-np.sqrt(6.0 / (1 + H)), np.sqrt(6.0 / (1 + H)), (1, H)).astype(np.float32),
+                bias=(0.3 * g.standard_normal(H)).astype(np.float32))
+
+
+def _run_neural(lat, p):
+    return ops.backward_neural(lat, *(torch.from_numpy(p[k]) for k in ("emb", "Wx", "Wh", "W", "bias")))
+
+
+@pytest.mark.parametrize("name", NEURAL)
+def test_beta_neural_matches_reference_fixture(dev, golden_dir, name):
+    """compute_beta_per_sample with Wh != 0 (scorers.py:692-751), values produced by the reference."""
+    with np.load(os.path.join(golden_dir, "beta_neural.npz")) as g:
+        c = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+    n_rows = int(c["n_rows"])
+    lat = LatticeBatch.from_arcs([n_rows], [0, c["src"].shape[0]], c["src"], c["label"], c["dst"], c["emb"].shape[0], device=dev)
+    r = _run_neural(lat, c)
+    got = r.log_beta.cpu().numpy().astype(np.float64)
+    ref = c["beta_per_sample"].astype(np.float64)
+    np.testing.assert_allclose(np.exp(got), ref, rtol=5e-5)  # the reference itself is float32
+    logb, bhat = O.beta_neural(n_rows, c["src"], c["label"], c["dst"], c["emb"], c["Wx"], c["Wh"], c["W"], c["bias"])
+    assert np.max(np.abs(got - logb)) <= 2e-5
+    assert np.max(np.abs(r.beta_hat.cpu().numpy() - bhat)) <= 2e-5
+
+
+@pytest.mark.parametrize("H", [8, 64, 100, 256, 512])
+def test_beta_neural_against_oracle(dev, H):
+    """Mixed batch (sizes, a 200-way fan-out and fan-in, weighted tables) under every packing the
+    host can choose: carry pieces and partial groups merge (beta, beta_hat) by weight."""
+    V = 256
+    src = [0] + [1] * 200 + list(range(2, 202)) + [202]
+    lab = [BOS] + list(range(3, 203)) + [5] * 200 + [EOS]
+    dst = [1] + list(range(2, 202)) + [202] * 200 + [203]
+    star = synth._finish(204, V, src, lab, dst)
+    lats = [star, synth.layered_lattice(51, n_states=150, avg_degree=6.0, vocab=V, width=4, span=3),
+            synth.layered_lattice(52, n_states=60, avg_degree=3.0, vocab=V, width=1, span=2),
+            synth.layered_lattice(53, n_states=300, avg_degree=12.0, vocab=V, width=24, span=2, max_degree=40)]
+    p = _neural_params(H, V, H, scale=2.0)
+    refs = [O.beta_neural(l.n_rows, l.src, l.label, l.dst, p["emb"], p["Wx"], p["Wh"], p["W"], p["bias"]) for l in lats]
+    all_opts = (dict(), dict(slots_per_lane=1), dict(slots_per_lane=2, group_mode=1), dict(slots_per_lane=4, no_compact=True),
+                dict(group_mode=2)) if H in (8, 256) else (dict(), dict(group_mode=1, slots_per_lane=1))
+    for opts in all_opts:
+        lat = LatticeBatch.from_synth(lats, device=dev, **opts)
+        r = _run_neural(lat, p)
+        lb, bh = r.log_beta.cpu().numpy().astype(np.float64), r.beta_hat.cpu().numpy()
+        for b, (l, (logb, bhat)) in enumerate(zip(lats, refs)):
+            r0 = int(lat.row_off[b])
+            cmp_rows(lb[r0:r0 + l.n_rows], logb, tol=3e-5)
+            assert np.max(np.abs(bh[r0:r0 + l.n_rows] - bhat)) <= 3e-5, (H, opts, b)
+
+
+def test_beta_neural_weighted_tables_and_zero_wh(dev):
+    """Weighted tables add their arc weight to the compatibility score; with Wh = 0 the sweep is
+    the plain beta sweep with theta[l] = W . tanh(Wx e(l) + bias)."""
+    V, H = 64, 16
+    lats = [synth.layered_lattice(61 + i, n_states=80 + 40 * i, avg_degree=5.0, vocab=V, width=3, span=3, weighted=True) for i in range(3)]
+    p = _neural_params(5, V, H)
+    p["Wh"][:] = 0
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    r = _run_neural(lat, p)
+    theta = (np.tanh(p["emb"].astype(np.float64) @ p["Wx"].T.astype(np.float64) + p["bias"]) @ p["W"].reshape(-1).astype(np.float64))
+    plain = ops.backward(lat, torch.from_numpy(theta.astype(np.float32)))
+    assert torch.max(torch.abs(r.log_beta - plain.logbeta)[torch.isfinite(plain.logbeta)]) <= 2e-5
+    for b, l in enumerate(lats):
+        o, _ = oracle_fb(l, theta)
+        r0 = int(lat.row_off[b])
+        cmp_rows(r.log_beta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tol=2e-5)
+    with pytest.raises(ValueError):
+        ops.backward_neural(lat, torch.zeros(V, H), torch.zeros(H, H), torch.zeros(H + 1, H), torch.zeros(H), torch.zeros(H))
