@@ -303,13 +303,13 @@ int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_
  *     t   = tanh(label_x[l] + Wh . beta_hat(s')),  label_x[l] = Wx . e(l) + bias
  *     msg = exp(w . t (+ arc_w)) * beta(s')
  *     beta(s) = sum msg,  beta_hat(s) = sum (msg / beta(s)) t;  beta(sink) = 1, beta_hat(sink) = 0.
- * label_x: device float32 [vocab, hid]; wh_t: Wh transposed, [hid (in), hid (out)]
- * row-major; w: [hid]; hid <= 512.  Outputs: log_beta [total_rows] (natural log;
+ * label_x: device float32 [vocab, hid]; wh: Wh as the reference holds it, [hid (out),
+ * hid (in)] row-major; w: [hid]; hid <= 512.  Outputs: log_beta [total_rows] (natural log;
  * the reference returns exp of it), beta_hat [total_rows, hid].  ws: device
  * workspace of nfst_neural_ws_floats() floats, contents irrelevant.
  */
 int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid);
-int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w,
+int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh, const float *w,
                          int32_t hid, float *log_beta, float *beta_hat, float *ws, void *stream);
 
 /* out[a] = theta[(theta_stride * b) + label[a]] (+ arc_w[a]) (+ arc_scores[a]) */

@@ -291,18 +291,18 @@ int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid) {
   return 2 * (int64_t)lat->n_lattices * lat->max_rows * hid;
 }
 
-int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w, int32_t hid,
+int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh, const float *w, int32_t hid,
                          float *log_beta, float *beta_hat, float *ws, void *stream) {
   int rc = check_batch(lat);
   if (rc) return rc;
-  if (!label_x || !wh_t || !w || !log_beta || !beta_hat || !ws || hid <= 0) return NFST_ERR_ARG;
+  if (!label_x || !wh || !w || !log_beta || !beta_hat || !ws || hid <= 0) return NFST_ERR_ARG;
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   const int64_t lds = NeuLds(lat->max_rows, hid).bytes();
 #define NFST_LAUNCH_NEU(HC)                                                                                   \
   do {                                                                                                        \
     if ((rc = set_lds(k_backward_neural<HC>, lds))) return rc;                                                \
     hipLaunchKernelGGL(k_backward_neural<HC>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,          \
-                       (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, log_beta, beta_hat, ws);        \
+                       (hipStream_t)stream, *lat, label_x, wh, w, (int)hid, log_beta, beta_hat, ws);        \
   } while (0)
   if (hid <= 64) NFST_LAUNCH_NEU(1);
   else if (hid <= 128) NFST_LAUNCH_NEU(2);

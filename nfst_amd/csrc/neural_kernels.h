@@ -13,21 +13,23 @@
 // groups of a tile are independent, so every tile is
 //   A  one wave per group: lanes hold the H components, the group's records are summed into
 //      (mantissa, exponent) + an H-vector scaled by the same exponent -- no exp/log of beta;
-//   B  u(s) = Wh . beta_hat(s) for the states the tile finished, all of them against one pass
-//      over Wh (columns on threads, up to 8 states per thread in registers, beta_hat broadcast
-//      from LDS) -- the per-state H x H product is what dominates at H = 256.
+//   B  u(s) = Wh . beta_hat(s) for the states the tile finished, 16 of them against one pass over
+//      Wh, as float32 MFMA (16x16x4) -- the per-state H x H product is what dominates at H = 256,
+//      and Wh (256 KiB there) has to come from L2 once per pass.
 // A unit-label record (carry of a continuation piece, or the scratch row of a partial group)
 // contributes the row's own (beta, beta_hat): beta_hat is a beta-weighted mean, so pieces merge
 // by weight.
 #pragma once
 
-constexpr int kNeuThreads = 1024, kNeuWaves = kNeuThreads / 64, kNeuChunk = 16, kNeuMaxHid = 512;
+constexpr int kNeuThreads = 1024, kNeuWaves = kNeuThreads / 64, kNeuRows = 32, kNeuMaxHid = 512;
 
 struct NeuLds {
   int rows, hid;
   __host__ __device__ NeuLds(int r, int h) : rows(r), hid(h) {}
-  // float2 beta[rows] | u32 ctl[64] | u32 rec[256] | i32 cas[256] | i32 lead[64] | i32 n_lead[4] | float bh[16 * hid]
-  __host__ __device__ int64_t bytes() const { return (int64_t)rows * 8 + (64 + 256 + 256 + 64 + 4) * 4 + (int64_t)kNeuChunk * hid * 4; }
+  // multiple of 16 (the K loop of phase B) + 4 floats so that the 16 rows of a pass start in different banks
+  __host__ __device__ static int row_stride(int h) { return ((h + 15) & ~15) + 4; }
+  // float2 beta[rows] | u32 ctl[64] | u32 rec[256] | i32 cas[256] | i32 lead[64] | i32 n_lead[4] | float bh[32][row_stride]
+  __host__ __device__ int64_t bytes() const { return (int64_t)rows * 8 + (64 + 256 + 256 + 64 + 4) * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
 };
 
 // 2^-d for d >= 0 (0 when the term is too small to matter)
@@ -35,7 +37,7 @@ __device__ __forceinline__ float neu_scale(int d) { return d > 120 ? 0.0f : __in
 
 template <int HC>  // components per lane: hid <= 64 * HC
 __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat, const float *__restrict__ label_x,
-                                                                 const float *__restrict__ wh_t,
+                                                                 const float *__restrict__ wh,
                                                                  const float *__restrict__ wvec, int hid,
                                                                  float *__restrict__ log_beta,
                                                                  float *__restrict__ beta_hat, float *ws) {
@@ -72,37 +74,55 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   __threadfence_block();
   __syncthreads();
 
-  // phase-B thread layout: column k of Wh^T, thread row tr; thread rows share the chunk's states
-  const int hp = (hid + 63) & ~63, TR = kNeuThreads / hp;
-  const int kcol = tid % hp, trow = tid / hp;
+  const int hs = NeuLds::row_stride(hid);  // LDS row of one state's beta_hat: zero beyond hid
+  for (int i = tid; i < kNeuRows * hs; i += kNeuThreads) bh_s[i] = 0.0f;
+  __syncthreads();
+
+  // the words of tile T+1 are fetched while tile T is computed
+  struct Fetch { uint4 x; uint32_t w; };
+  auto fetch = [&](int T) {
+    Fetch f;
+    f.x = make_uint4(0, 0, 0, 0);
+    f.w = 0;
+    if (T >= m.bwd_tiles) return f;
+    if (tid < 64) {
+      if (F == 8) f.x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + tid * 4);
+      else f.w = prog[(size_t)T * ST + tid];
+    } else if (tid < 64 + 64 * U) {
+      if (F != 8) f.w = prog[(size_t)T * ST + tid];
+    } else if (tid >= 512 && tid < 512 + 64 * U) {
+      f.w = (uint32_t)perm[(size_t)T * 64 * U + (tid - 512)];
+    }
+    return f;
+  };
+  Fetch nx = fetch(0);
 
   for (int T = 0; T < m.bwd_tiles; ++T) {
     // ---- stage the tile's words: control words, records as 32-bit words, slot -> arc map
     if (tid < 64) {
+      uint32_t c = nx.w;
       if (F == 8) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + tid * 4);
-        ctl_s[tid] = x.x;
+        const uint4 x = nx.x;
+        c = x.x;
         const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
 #pragma unroll
         for (int j = 0; j < 4; ++j) rec_s[tid * 4 + j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);
-      } else {
-        ctl_s[tid] = prog[(size_t)T * ST + tid];
       }
-      const uint32_t c = ctl_s[tid];
+      ctl_s[tid] = c;
       const uint64_t leaders = __builtin_amdgcn_ballot_w64((c >> 31) != 0);
       if (c >> 31) lead_s[__builtin_popcountll(leaders & ((1ull << tid) - 1))] = tid;
       if (tid == 0) nlead_s[0] = __builtin_popcountll(leaders);
     } else if (tid < 64 + 64 * U) {
-      const int q = tid - 64;
-      if (F != 8) rec_s[q] = prog[(size_t)T * ST + 64 + q];
+      if (F != 8) rec_s[tid - 64] = nx.w;
     } else if (tid >= 512 && tid < 512 + 64 * U) {
-      const int q = tid - 512;
-      cas_s[q] = perm[(size_t)T * 64 * U + q];
+      cas_s[tid - 512] = (int)nx.w;
     }
     __syncthreads();
+    nx = fetch(T + 1);
     const int n_lead = nlead_s[0];
 
-    // ---- A: one wave per group
+    // ---- A: one wave per group.  The operands of the group's next record are in flight while
+    // the current one is computed (they come from L2: label table, u and beta_hat rows).
     for (int i = wv; i < n_lead; i += kNeuWaves) {
       const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
@@ -111,98 +131,147 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
       int eacc = kEZero;
 #pragma unroll
       for (int c = 0; c < HC; ++c) tacc[c] = 0.0f;
-      for (int r = 0; r < n_rec; ++r) {
-        const int q = l0 * U + r;
-        const uint32_t rc = __builtin_amdgcn_readfirstlane(rec_s[q]);
-        const int ca = __builtin_amdgcn_readfirstlane(cas_s[q]);
-        const int other = (int)((rc & 0xffffu) >> 3), lab = (int)(rc >> 16);
-        float vec[HC];
-        float wm;
-        int we;
-        if (ca >= 0) {
-          float part = 0.0f;
+      for (int q0 = 0; q0 < n_rec; q0 += 64) {
+        // lanes look at one record each: which of them carry anything
+        uint32_t rc_l = 0;
+        int ca_l = -1;
+        if (q0 + lane < n_rec) { rc_l = rec_s[l0 * U + q0 + lane]; ca_l = cas_s[l0 * U + q0 + lane]; }
+        uint64_t todo = __builtin_amdgcn_ballot_w64(ca_l >= 0 || (int)(rc_l >> 16) == V + 1);
+        struct Ops { float a[HC], b[HC]; uint32_t rc; int ca; };
+        auto issue = [&](int p) {
+          Ops o;
+          o.rc = (uint32_t)__builtin_amdgcn_readlane((int)rc_l, p);
+          o.ca = __builtin_amdgcn_readlane(ca_l, p);
+          const int other = (int)((o.rc & 0xffffu) >> 3), lab = (int)(o.rc >> 16);
+          const float *pa = o.ca >= 0 ? label_x + (size_t)lab * hid : bh_w + (size_t)other * hid;
+          const float *pb = u_w + (size_t)other * hid;
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
             const int h = c * 64 + lane;
-            float t = 0.0f;
-            if (h < hid) t = tanhf(label_x[(size_t)lab * hid + h] + u_w[(size_t)other * hid + h]);
-            vec[c] = t;
-            part = fmaf(wl[c], t, part);
+            o.a[c] = (h < hid) ? pa[h] : 0.0f;
+            o.b[c] = (h < hid && o.ca >= 0) ? pb[h] : 0.0f;
           }
-          float score = wave_sum(part);
-          if (arc_w) score += arc_w[ca];
-          const ME w = exp_split(score);
+          return o;
+        };
+        Ops cur;
+        if (todo) cur = issue(__builtin_ctzll(todo));
+        while (todo) {
+          todo &= todo - 1;
+          Ops nxt;
+          if (todo) nxt = issue(__builtin_ctzll(todo));
+          const int other = (int)((cur.rc & 0xffffu) >> 3);
           const float2 bo = bme[other];
-          wm = w.m * bo.x;
-          we = w.e + __float_as_int(bo.y);
-        } else if (lab == V + 1) {  // what row `other` holds: own earlier pieces, or a partial group's scratch row
-          const float2 bo = bme[other];
-          wm = bo.x;
-          we = __float_as_int(bo.y);
+          float vec[HC];
+          float wm = bo.x;
+          int we = __float_as_int(bo.y);
+          if (cur.ca >= 0) {
+            float part = 0.0f;
 #pragma unroll
-          for (int c = 0; c < HC; ++c) {
-            const int h = c * 64 + lane;
-            vec[c] = (h < hid) ? bh_w[(size_t)other * hid + h] : 0.0f;
+            for (int c = 0; c < HC; ++c) {
+              vec[c] = (c * 64 + lane < hid) ? tanhf(cur.a[c] + cur.b[c]) : 0.0f;
+              part = fmaf(wl[c], vec[c], part);
+            }
+            float score = wave_sum(part);
+            if (arc_w) score += arc_w[cur.ca];
+            const ME w = exp_split(score);
+            wm *= w.m;
+            we += w.e;
+          } else {  // what row `other` holds: own earlier pieces, or a partial group's scratch row
+#pragma unroll
+            for (int c = 0; c < HC; ++c) vec[c] = cur.a[c];
           }
-        } else {
-          continue;  // empty slot
-        }
-        if (!(wm > 0.0f)) continue;
-        we = max(we, kEZero);
-        if (we > eacc) {
-          const float s = neu_scale(we - eacc);
-          macc *= s;
+          if (wm > 0.0f) {
+            we = max(we, kEZero);
+            if (we > eacc) {
+              const float sc = neu_scale(we - eacc);
+              macc *= sc;
 #pragma unroll
-          for (int c = 0; c < HC; ++c) tacc[c] *= s;
-          eacc = we;
-        }
-        wm *= neu_scale(eacc - we);
-        macc += wm;
+              for (int c = 0; c < HC; ++c) tacc[c] *= sc;
+              eacc = we;
+            }
+            wm *= neu_scale(eacc - we);
+            macc += wm;
 #pragma unroll
-        for (int c = 0; c < HC; ++c) tacc[c] = fmaf(wm, vec[c], tacc[c]);
+            for (int c = 0; c < HC; ++c) tacc[c] = fmaf(wm, vec[c], tacc[c]);
+          }
+          if (todo) cur = nxt;
+        }
       }
       const float inv = macc > 0.0f ? 1.0f / macc : 0.0f;
 #pragma unroll
       for (int c = 0; c < HC; ++c) {
         const int h = c * 64 + lane;
-        if (h < hid) bh_w[(size_t)sid * hid + h] = tacc[c] * inv;
+        if (h < hid) {
+          bh_w[(size_t)sid * hid + h] = tacc[c] * inv;
+          if (i < kNeuRows) bh_s[i * hs + h] = tacc[c] * inv;
+        }
       }
       if (lane == 0) bme[sid] = me_pack(macc, eacc);
     }
-    __threadfence_block();
     __syncthreads();
 
-    // ---- B: u = Wh . beta_hat for the states this tile wrote (scratch rows need none)
-    for (int g0 = 0; g0 < n_lead; g0 += kNeuChunk) {
-      const int n = min(kNeuChunk, n_lead - g0);
-      for (int i = tid; i < n * hid; i += kNeuThreads) {
-        const int g = i / hid, h = i - g * hid;
-        const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
-        bh_s[g * hid + h] = bh_w[(size_t)sid * hid + h];
+    // ---- B: u = Wh . beta_hat for the states this tile wrote, 16 of them per pass over Wh:
+    // D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32, one block of
+    // 16 columns per wave.  A comes from the LDS rows phase A filled, B straight from Wh (L2).
+    for (int g0 = 0; g0 < n_lead; g0 += 16) {
+      const int n = min(16, n_lead - g0);
+      const float *rows = bh_s + (size_t)g0 * hs;
+      if (g0 + 16 > kNeuRows) {  // more groups in the tile than LDS rows: fetch theirs from the workspace
+        __syncthreads();
+        for (int i = tid; i < n * hid; i += kNeuThreads) {
+          const int g = i / hid, h = i - g * hid;
+          const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
+          bh_s[g * hs + h] = bh_w[(size_t)sid * hid + h];
+        }
+        __syncthreads();
+        rows = bh_s;
       }
-      __syncthreads();
-      if (kcol < hid && trow < TR) {
-        float acc[8];
+      const int li = lane & 15, kq = lane >> 4;
+      for (int ct = wv; ct * 16 < hid; ct += kNeuWaves) {
+        const int col = ct * 16 + li;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if ((hid & 15) == 0) {
+          const float *bp = wh + (size_t)col * hid + 4 * kq;
+          const float *ap = rows + li * hs + 4 * kq;
+          int h = 0;
+          for (; h + 64 <= hid; h += 64) {  // four 16-byte loads of Wh in flight per lane
+            float4 bq[4], aq[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-        for (int h = 0; h < hid; ++h) {
-          const float w = wh_t[(size_t)h * hid + kcol];
+            for (int d = 0; d < 4; ++d) bq[d] = *reinterpret_cast<const float4 *>(bp + h + 16 * d);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int g = trow + j * TR;
-            if (g < n) acc[j] = fmaf(w, bh_s[g * hid + h], acc[j]);
+            for (int d = 0; d < 4; ++d) aq[d] = *reinterpret_cast<const float4 *>(ap + h + 16 * d);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].x, bq[d].x, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].y, bq[d].y, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].z, bq[d].z, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].w, bq[d].w, acc, 0, 0, 0);
+            }
+          }
+          for (; h < hid; h += 16) {
+            const float4 bq = *reinterpret_cast<const float4 *>(bp + h);
+            const float4 aq = *reinterpret_cast<const float4 *>(ap + h);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq.w, acc, 0, 0, 0);
+          }
+        } else {
+          for (int h = 0; h < hid; h += 4) {  // the LDS rows are zero beyond hid
+            const float bv = (col < hid && h + kq < hid) ? wh[(size_t)col * hid + h + kq] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rows[li * hs + h + kq], bv, acc, 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int g = trow + j * TR;
-          if (g < n) {
+        for (int r = 0; r < 4; ++r) {  // lane holds D[4 kq + r][li]
+          const int g = 4 * kq + r;
+          if (g < n && col < hid) {
             const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
-            if (sid < m.n_rows) u_w[(size_t)sid * hid + kcol] = acc[j];
+            if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = acc[r];
           }
         }
       }
-      __syncthreads();
     }
     __threadfence_block();
     __syncthreads();

@@ -349,12 +349,12 @@ def backward_neural(lat: LatticeBatch, emb: torch.Tensor, Wx: torch.Tensor, Wh: 
     if emb.shape != (lat.vocab, H) or Wx.shape != (H, H) or Wh.shape != (H, H) or bias.shape != (H,):
         raise ValueError("emb must be [V, H], Wx and Wh [H, H], W [H] and bias [H]")
     label_x = torch.addmm(bias, emb, Wx.t()).contiguous()
-    wh_t = Wh.t().contiguous()
+    wh = Wh.contiguous()
     s = lat.c_struct()
     ws = torch.empty(int(lib.nfst_neural_ws_floats(C.byref(s), H)), **f32)
     log_beta = torch.empty(lat.total_rows, **f32)
     beta_hat = torch.empty(lat.total_rows, H, **f32)
-    check(lib.nfst_backward_neural(C.byref(s), label_x.data_ptr(), wh_t.data_ptr(), w.data_ptr(), H, log_beta.data_ptr(),
+    check(lib.nfst_backward_neural(C.byref(s), label_x.data_ptr(), wh.data_ptr(), w.data_ptr(), H, log_beta.data_ptr(),
                                    beta_hat.data_ptr(), ws.data_ptr(), _stream()), "nfst_backward_neural")
     return NeuralBeta(log_beta, beta_hat)
 

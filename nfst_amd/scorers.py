@@ -100,3 +100,33 @@ class LatticeScorer(torch.nn.Module):
 
     def forward(self, sequence: torch.Tensor, **kwargs):
         return self.wfst_score(sequence)
+
+
+class NeuralBetaScorer(LatticeScorer):
+    """The ``use_beta=True`` part of ``FSAGRUScorer`` (scorers.py:954-970): parameters ``Wh``, ``Wx``
+    [H, H], ``W`` [1, H], ``beta_bias`` [H] and the mark ``embeddings`` [V, H], initialised as
+    there; ``compute_beta`` is the message-passing sweep of scorers.py:692-751 / 753-856 on the HIP
+    engine (``ops.backward_neural``) and follows the per-sample semantics -- parallel arcs between
+    a state pair count once each."""
+
+    def __init__(self, hid_dim: int, vocab_size: int, **kw):
+        super().__init__(vocab_size, **kw)
+        self.hid_dim = hid_dim
+        self.embeddings = torch.nn.Embedding(vocab_size, hid_dim)
+        self.Wh = torch.nn.Parameter(torch.empty(hid_dim, hid_dim))
+        self.Wx = torch.nn.Parameter(torch.empty(hid_dim, hid_dim))
+        self.W = torch.nn.Parameter(torch.empty(1, hid_dim))
+        for p in (self.Wh, self.Wx, self.W):
+            torch.nn.init.xavier_uniform_(p)
+        self.beta_bias = torch.nn.Parameter(torch.zeros(hid_dim))
+
+    def compute_beta_hat(self):
+        """``(log beta [B*k, S+1], beta_hat [B*k, S+1, H])``."""
+        lat = self._lat()
+        with torch.no_grad():
+            r = ops.backward_neural(lat, self.embeddings.weight, self.Wx, self.Wh, self.W, self.beta_bias)
+        return (lat.rows_view(r.log_beta).repeat_interleave(self.k, dim=0),
+                lat.rows_view(r.beta_hat).repeat_interleave(self.k, dim=0))
+
+    def compute_log_beta(self) -> torch.Tensor:
+        return self.compute_beta_hat()[0]

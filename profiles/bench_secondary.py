@@ -39,4 +39,15 @@ t = timeit(lambda: ops.emission_mask(lat, st, k=64, inp=lb))
 out["emission_mask_K64"] = {"ms": t * 1e3, "GB/s_written": 256 * 64 * 256 * 4 / t / 1e9}
 t = timeit(lambda: ops.gather_label_scores(lat, theta))
 out["gather_label_scores"] = {"ms": t * 1e3, "GB/s": lat.total_arcs * 8 / t / 1e9}
+# neuralised beta: hid_dim of the reference's configs (conf/train/*.yaml: 256) and a small one
+for H in (256, 64, 8):
+    g = torch.Generator(device="cpu").manual_seed(H)
+    lim = (6.0 / (2 * H)) ** 0.5
+    prm = [torch.randn(256, H, generator=g), (torch.rand(H, H, generator=g) * 2 - 1) * lim, (torch.rand(H, H, generator=g) * 2 - 1) * lim,
+           (torch.rand(1, H, generator=g) * 2 - 1) * (6.0 / (1 + H)) ** 0.5, 0.3 * torch.randn(H, generator=g)]
+    prm = [x.to(dev) for x in prm]
+    t = timeit(lambda: ops.backward_neural(lat, *prm), n=5, w=1)
+    states = int(lat.meta_host[:, 9].sum())
+    out[f"backward_neural_H{H}"] = {"ms": t * 1e3, "arcs/s": arcs / t,
+                                   "GFLOP/s": (2.0 * states * H * H + 4.0 * arcs * H) / t / 1e9}
 print(json.dumps(out, indent=1))

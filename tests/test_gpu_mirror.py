@@ -133,3 +133,29 @@ def test_joint_prob_forward_and_decode(dev, tmp_path):
     jp2 = JointProb(V, pad=PAD, bos=BOS, eos=EOS, k=8, theta=torch.from_numpy(theta), exact=False).to(dev)
     num2, _ = jp2(*tb)
     assert torch.max(torch.abs(num2 - (num.detach() - float(theta[BOS])))) <= 5e-5
+
+
+def test_neural_beta_scorer_matches_reference(dev, golden_dir):
+    """NeuralBetaScorer.compute_beta == FSAGRUScorer.compute_beta_per_sample with the reference's own
+    parameters (Wh != 0), called the way Sampler.stateful_sample calls it (samplers.py:196-198)."""
+    from nfst_amd.scorers import NeuralBetaScorer
+    name = "neural_layered40_h16"
+    with np.load(os.path.join(golden_dir, "beta_neural.npz")) as g:
+        c = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+    V, H = c["emb"].shape
+    sc = NeuralBetaScorer(H, V, pad=PAD, bos=BOS, eos=EOS).to(dev)
+    with torch.no_grad():
+        sc.embeddings.weight.copy_(torch.from_numpy(c["emb"]))
+        for k, p in (("Wx", sc.Wx), ("Wh", sc.Wh), ("W", sc.W), ("bias", sc.beta_bias)):
+            p.copy_(torch.from_numpy(c[k]))
+    tr = c["transition"]
+    em = tr != 0
+    em[-1, PAD] = True  # the sink's pad self loop (scorers.py:1013-1016)
+    tr = tr.copy(); tr[-1, PAD] = tr.shape[0] - 1
+    sc.set_masks(emission=torch.from_numpy(em)[None], transition=torch.from_numpy(tr)[None])
+    sc.set_k(3)
+    beta = sc.compute_beta().cpu().numpy()
+    assert beta.shape == (3, tr.shape[0]) and np.array_equal(beta[0], beta[2])
+    np.testing.assert_allclose(beta[0], c["beta_per_sample"], rtol=5e-5)
+    _, bhat = sc.compute_beta_hat()
+    assert bhat.shape == (3, tr.shape[0], H) and float(bhat.abs().max()) <= 1.0
