@@ -9,28 +9,51 @@
 //     beta(s)     = sum msg,    beta_hat(s) = sum (msg / beta(s)) t(arc)
 //     beta(sink)  = 1,          beta_hat(sink) = 0
 //
-// One workgroup per lattice walks the beta tile program tile by tile; the
-// groups of a tile are independent, so every tile is
-//   A  one wave per group: lanes hold the H components, the group's records are summed into
-//      (mantissa, exponent) + an H-vector scaled by the same exponent -- no exp/log of beta;
+// One workgroup (16 waves) per lattice walks the beta tile program tile by
+// tile; the groups of a tile are independent, so every tile is
+//   A  one wave per group, lanes over the H components.  Records go D at a time: all operand rows
+//      (label table, u and beta_hat rows -- L2 hits) are requested first, tanh and W . t run per
+//      record on all lanes, and what is one number per record (exp, times beta of the operand,
+//      common exponent) runs once per batch with one record per lane.  The group's sum is a
+//      (mantissa, exponent) pair plus an H-vector scaled by the same exponent: no exp/log of beta.
 //   B  u(s) = Wh . beta_hat(s) for the states the tile finished, 16 of them against one pass over
-//      Wh, as float32 MFMA (16x16x4) -- the per-state H x H product is what dominates at H = 256,
-//      and Wh (256 KiB there) has to come from L2 once per pass.
+//      Wh, as float32 MFMA (16x16x4): the per-state H x H product is what dominates at H = 256,
+//      and Wh (256 KiB there) comes from L2 once per pass.  beta_hat rows go from phase A to
+//      phase B through LDS.
+// The last wave takes no part in A: it stages the next tile's words (an HBM miss) meanwhile.
 // A unit-label record (carry of a continuation piece, or the scratch row of a partial group)
 // contributes the row's own (beta, beta_hat): beta_hat is a beta-weighted mean, so pieces merge
 // by weight.
 #pragma once
 
 constexpr int kNeuThreads = 1024, kNeuWaves = kNeuThreads / 64, kNeuRows = 32, kNeuMaxHid = 512;
+constexpr int kNeuStageWords = 64 + 256 + 256 + 64 + 4;  // ctl | rec | slot -> arc | leaders | their count
 
 struct NeuLds {
   int rows, hid;
   __host__ __device__ NeuLds(int r, int h) : rows(r), hid(h) {}
   // multiple of 16 (the K loop of phase B) + 4 floats so that the 16 rows of a pass start in different banks
   __host__ __device__ static int row_stride(int h) { return ((h + 15) & ~15) + 4; }
-  // float2 beta[rows] | u32 ctl[64] | u32 rec[256] | i32 cas[256] | i32 lead[64] | i32 n_lead[4] | float bh[32][row_stride]
-  __host__ __device__ int64_t bytes() const { return (int64_t)rows * 8 + (64 + 256 + 256 + 64 + 4) * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
+  // float2 beta[rows] | two staged tiles | float bh[32][row_stride]
+  __host__ __device__ int64_t bytes() const { return (int64_t)rows * 8 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
 };
+
+// tanh(x) = 1 - 2 / (e^2x + 1) on the hardware exp2 and reciprocal: absolute error below 2e-7 over
+// the whole line (the messages are bounded by 1 and enter sums, so absolute error is what counts)
+__device__ __forceinline__ float neu_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+  v = max(v, dpp_i<0xB1>(v));
+  v = max(v, dpp_i<0x4E>(v));
+  v = max(v, dpp_i<0x141>(v));
+  v = max(v, dpp_i<0x140>(v));
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
+            d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
 
 // 2^-d for d >= 0 (0 when the term is too small to matter)
 __device__ __forceinline__ float neu_scale(int d) { return d > 120 ? 0.0f : __int_as_float((127 - d) << 23); }
@@ -40,21 +63,20 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
                                                                  const float *__restrict__ wh,
                                                                  const float *__restrict__ wvec, int hid,
                                                                  float *__restrict__ log_beta,
-                                                                 float *__restrict__ beta_hat, float *ws) {
+                                                                 float *beta_hat, float *ws) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
   float2 *bme = lds;
-  uint32_t *ctl_s = (uint32_t *)(bme + lat.max_rows);
-  uint32_t *rec_s = ctl_s + 64;
-  int *cas_s = (int *)(rec_s + 256);
-  int *lead_s = cas_s + 256;
-  int *nlead_s = lead_s + 64;
-  float *bh_s = (float *)(nlead_s + 4);
-  // workspace rows of this lattice: beta_hat (also of scratch rows), then u = Wh . beta_hat
+  uint32_t *stage_s = (uint32_t *)(bme + lat.max_rows);  // two tiles: kNeuStageWords each
+  float *bh_s = (float *)(stage_s + 2 * kNeuStageWords);
+  // beta_hat of a real row lives in the output array, that of a scratch row (partial groups of the
+  // tile program) in the workspace; u = Wh . beta_hat of the real rows in the workspace
   float *bh_w = ws + (size_t)b * lat.max_rows * hid;
   float *u_w = ws + ((size_t)lat.n_lattices + b) * lat.max_rows * hid;
+  float *bh_out = beta_hat + (size_t)m.row_off * hid;
+  auto bh_row = [&](int r) { return r < m.n_rows ? bh_out + (size_t)r * hid : bh_w + (size_t)r * hid; };
   const int F = m.bwd_u, U = fmt_u(F), ST = fmt_words(F);
   const uint32_t *prog = lat.bwd_stream + m.bwd_off;
   const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
@@ -63,7 +85,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
 
   for (int i = tid; i < lat.max_rows; i += kNeuThreads) bme[i] = make_float2(0.0f, __int_as_float(kEZero));
   for (int i = tid; i < hid; i += kNeuThreads) {
-    bh_w[(size_t)m.sink * hid + i] = 0.0f;
+    bh_out[(size_t)m.sink * hid + i] = 0.0f;
     u_w[(size_t)m.sink * hid + i] = 0.0f;
   }
   float wl[HC];
@@ -78,52 +100,42 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   for (int i = tid; i < kNeuRows * hs; i += kNeuThreads) bh_s[i] = 0.0f;
   __syncthreads();
 
-  // the words of tile T+1 are fetched while tile T is computed
-  struct Fetch { uint4 x; uint32_t w; };
-  auto fetch = [&](int T) {
-    Fetch f;
-    f.x = make_uint4(0, 0, 0, 0);
-    f.w = 0;
-    if (T >= m.bwd_tiles) return f;
-    if (tid < 64) {
-      if (F == 8) f.x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + tid * 4);
-      else f.w = prog[(size_t)T * ST + tid];
-    } else if (tid < 64 + 64 * U) {
-      if (F != 8) f.w = prog[(size_t)T * ST + tid];
-    } else if (tid >= 512 && tid < 512 + 64 * U) {
-      f.w = (uint32_t)perm[(size_t)T * 64 * U + (tid - 512)];
+  // The last wave stages tile T+1 (control words, records as 32-bit words, slot -> arc map, list
+  // of group leaders) while the others run phase A of tile T: its loads miss to HBM, and a wave's
+  // loads complete in order, so they must not sit in front of a computing wave's L2 hits.
+  auto stage_tile = [&](int T, uint32_t *st) {
+    uint32_t *ctl = st, *rec = st + 64;
+    int *cas = (int *)(st + 320), *lead = (int *)(st + 576), *nlead = (int *)(st + 640);
+    uint32_t c;
+    if (F == 8) {
+      const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
+      c = x.x;
+      const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rec[lane * 4 + j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);
+    } else {
+      c = prog[(size_t)T * ST + lane];
+      for (int j = 0; j < U; ++j) rec[lane + 64 * j] = prog[(size_t)T * ST + 64 + lane + 64 * j];
     }
-    return f;
+    for (int j = 0; j < U; ++j) cas[lane + 64 * j] = perm[(size_t)T * 64 * U + lane + 64 * j];
+    ctl[lane] = c;
+    const uint64_t leaders = __builtin_amdgcn_ballot_w64((c >> 31) != 0);
+    if (c >> 31) lead[__builtin_popcountll(leaders & ((1ull << lane) - 1))] = lane;
+    if (lane == 0) nlead[0] = __builtin_popcountll(leaders);
   };
-  Fetch nx = fetch(0);
+  if (wv == kNeuWaves - 1 && m.bwd_tiles > 0) stage_tile(0, stage_s);
+  __syncthreads();
 
   for (int T = 0; T < m.bwd_tiles; ++T) {
-    // ---- stage the tile's words: control words, records as 32-bit words, slot -> arc map
-    if (tid < 64) {
-      uint32_t c = nx.w;
-      if (F == 8) {
-        const uint4 x = nx.x;
-        c = x.x;
-        const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rec_s[tid * 4 + j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);
-      }
-      ctl_s[tid] = c;
-      const uint64_t leaders = __builtin_amdgcn_ballot_w64((c >> 31) != 0);
-      if (c >> 31) lead_s[__builtin_popcountll(leaders & ((1ull << tid) - 1))] = tid;
-      if (tid == 0) nlead_s[0] = __builtin_popcountll(leaders);
-    } else if (tid < 64 + 64 * U) {
-      if (F != 8) rec_s[tid - 64] = nx.w;
-    } else if (tid >= 512 && tid < 512 + 64 * U) {
-      cas_s[tid - 512] = (int)nx.w;
-    }
-    __syncthreads();
-    nx = fetch(T + 1);
+    uint32_t *st = stage_s + (T & 1) * kNeuStageWords;
+    const uint32_t *ctl_s = st, *rec_s = st + 64;
+    const int *cas_s = (const int *)(st + 320), *lead_s = (const int *)(st + 576), *nlead_s = (const int *)(st + 640);
+    if (wv == kNeuWaves - 1 && T + 1 < m.bwd_tiles) stage_tile(T + 1, stage_s + ((T + 1) & 1) * kNeuStageWords);
     const int n_lead = nlead_s[0];
 
     // ---- A: one wave per group.  The operands of the group's next record are in flight while
     // the current one is computed (they come from L2: label table, u and beta_hat rows).
-    for (int i = wv; i < n_lead; i += kNeuWaves) {
+    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
       const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
       const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
@@ -137,64 +149,90 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
         int ca_l = -1;
         if (q0 + lane < n_rec) { rc_l = rec_s[l0 * U + q0 + lane]; ca_l = cas_s[l0 * U + q0 + lane]; }
         uint64_t todo = __builtin_amdgcn_ballot_w64(ca_l >= 0 || (int)(rc_l >> 16) == V + 1);
-        struct Ops { float a[HC], b[HC]; uint32_t rc; int ca; };
+        const float x_l = arc_w ? arc_w[max(ca_l, 0)] : 0.0f;  // table weight of this lane's record
+        const int other_l = (int)((rc_l & 0xffffu) >> 3);
+        // Records are taken D at a time.  Their operands (L2 hits: label table, u and beta_hat
+        // rows) are all requested before the first is used -- one after the other each would cost
+        // a round trip.  The H-wide part (tanh, W . t) runs per record on all lanes; everything
+        // that is one number per record (exp, times beta of the operand, common exponent) runs
+        // once per batch with one record per lane.
+        struct Ops { float a[HC], b[HC]; int p, ca; };
+        constexpr int D = HC <= 2 ? 6 : (HC <= 4 ? 4 : 2);
+        // (straight-line on purpose: a conditional load makes the compiler wait for every load in
+        // flight where the branches join; a lane beyond hid re-reads the last component, a record
+        // without u reads one it ignores)
         auto issue = [&](int p) {
           Ops o;
-          o.rc = (uint32_t)__builtin_amdgcn_readlane((int)rc_l, p);
+          o.p = p;
+          const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)rc_l, p);
           o.ca = __builtin_amdgcn_readlane(ca_l, p);
-          const int other = (int)((o.rc & 0xffffu) >> 3), lab = (int)(o.rc >> 16);
-          const float *pa = o.ca >= 0 ? label_x + (size_t)lab * hid : bh_w + (size_t)other * hid;
+          const int other = (int)((rc & 0xffffu) >> 3), lab = (int)(rc >> 16);
+          const float *pa = o.ca >= 0 ? label_x + (size_t)lab * hid : bh_row(other);
           const float *pb = u_w + (size_t)other * hid;
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
-            const int h = c * 64 + lane;
-            o.a[c] = (h < hid) ? pa[h] : 0.0f;
-            o.b[c] = (h < hid && o.ca >= 0) ? pb[h] : 0.0f;
+            const int h = min(c * 64 + lane, hid - 1);
+            o.a[c] = pa[h];
+            o.b[c] = pb[h];
           }
           return o;
         };
-        Ops cur;
-        if (todo) cur = issue(__builtin_ctzll(todo));
         while (todo) {
-          todo &= todo - 1;
-          Ops nxt;
-          if (todo) nxt = issue(__builtin_ctzll(todo));
-          const int other = (int)((cur.rc & 0xffffu) >> 3);
-          const float2 bo = bme[other];
-          float vec[HC];
-          float wm = bo.x;
-          int we = __float_as_int(bo.y);
-          if (cur.ca >= 0) {
-            float part = 0.0f;
+          Ops buf[D];
+          uint64_t batch = 0;
+          int nb = 0, p = 0;
 #pragma unroll
-            for (int c = 0; c < HC; ++c) {
-              vec[c] = (c * 64 + lane < hid) ? tanhf(cur.a[c] + cur.b[c]) : 0.0f;
-              part = fmaf(wl[c], vec[c], part);
-            }
-            float score = wave_sum(part);
-            if (arc_w) score += arc_w[cur.ca];
-            const ME w = exp_split(score);
-            wm *= w.m;
-            we += w.e;
-          } else {  // what row `other` holds: own earlier pieces, or a partial group's scratch row
-#pragma unroll
-            for (int c = 0; c < HC; ++c) vec[c] = cur.a[c];
+          for (int k = 0; k < D; ++k) {  // past the last record: the last one again, ignored below
+            p = todo ? __builtin_ctzll(todo) : p;
+            nb += todo ? 1 : 0;
+            batch |= todo & (0 - todo);
+            todo &= todo - (todo ? 1 : 0);
+            buf[k] = issue(p);
           }
-          if (wm > 0.0f) {
-            we = max(we, kEZero);
-            if (we > eacc) {
-              const float sc = neu_scale(we - eacc);
-              macc *= sc;
+          float vec[D][HC];
+          float sc_l = 0.0f;
 #pragma unroll
-              for (int c = 0; c < HC; ++c) tacc[c] *= sc;
-              eacc = we;
+          for (int k = 0; k < D; ++k) {
+            if (k < nb) {
+              if (buf[k].ca >= 0) {
+                float part = 0.0f;
+#pragma unroll
+                for (int c = 0; c < HC; ++c) {
+                  const float t = neu_tanh(buf[k].a[c] + buf[k].b[c]);
+                  vec[k][c] = (c * 64 + lane < hid) ? t : 0.0f;
+                  part = fmaf(wl[c], vec[k][c], part);
+                }
+                const float sc = wave_sum(part);
+                sc_l = (lane == buf[k].p) ? sc : sc_l;
+              } else {  // what the operand row holds: own earlier pieces, or a partial group's scratch row
+#pragma unroll
+                for (int c = 0; c < HC; ++c) vec[k][c] = (c * 64 + lane < hid) ? buf[k].a[c] : 0.0f;
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < HC; ++c) vec[k][c] = 0.0f;
             }
-            wm *= neu_scale(eacc - we);
-            macc += wm;
-#pragma unroll
-            for (int c = 0; c < HC; ++c) tacc[c] = fmaf(wm, vec[c], tacc[c]);
           }
-          if (todo) cur = nxt;
+          // one record per lane
+          const bool act = (batch >> lane) & 1;
+          const float2 bo = bme[act ? other_l : 0];
+          const ME w = exp_split(sc_l + x_l);
+          float wm = act ? bo.x * (ca_l >= 0 ? w.m : 1.0f) : 0.0f;
+          int we = max(__float_as_int(bo.y) + (ca_l >= 0 ? w.e : 0), kEZero);
+          if (!(wm > 0.0f)) we = kEZero;
+          const int en = max(eacc, wave_max_i(we));
+          const float so = neu_scale(en - eacc);
+          const float q_l = wm * neu_scale(en - we);
+          macc = fmaf(macc, so, wave_sum(q_l));
+          eacc = en;
+#pragma unroll
+          for (int c = 0; c < HC; ++c) tacc[c] *= so;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float qk = k < nb ? read_lane_f(q_l, buf[k].p) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) tacc[c] = fmaf(qk, vec[k][c], tacc[c]);
+          }
         }
       }
       const float inv = macc > 0.0f ? 1.0f / macc : 0.0f;
@@ -202,7 +240,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
       for (int c = 0; c < HC; ++c) {
         const int h = c * 64 + lane;
         if (h < hid) {
-          bh_w[(size_t)sid * hid + h] = tacc[c] * inv;
+          bh_row(sid)[h] = tacc[c] * inv;
           if (i < kNeuRows) bh_s[i * hs + h] = tacc[c] * inv;
         }
       }
@@ -221,7 +259,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
         for (int i = tid; i < n * hid; i += kNeuThreads) {
           const int g = i / hid, h = i - g * hid;
           const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
-          bh_s[g * hs + h] = bh_w[(size_t)sid * hid + h];
+          bh_s[g * hs + h] = bh_row(sid)[h];
         }
         __syncthreads();
         rows = bh_s;
@@ -277,10 +315,9 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
     __syncthreads();
   }
 
-  // ---- outputs: log beta and beta_hat of the real rows (rows the program never wrote: -inf, 0)
+  // ---- outputs: log beta; beta_hat is in place (rows the program never wrote: -inf, 0)
   for (int r = tid; r < m.n_rows; r += kNeuThreads) log_beta[m.row_off + r] = me_log32(bme[r]);
-  for (int i = tid; i < m.n_rows * hid; i += kNeuThreads) {
-    const int r = i / hid;
-    beta_hat[(size_t)m.row_off * hid + i] = bme[r].x > 0.0f ? bh_w[i] : 0.0f;
-  }
+  for (int r = wv; r < m.n_rows; r += kNeuWaves)
+    if (!(bme[r].x > 0.0f))
+      for (int h = lane; h < hid; h += 64) bh_out[(size_t)r * hid + h] = 0.0f;
 }
