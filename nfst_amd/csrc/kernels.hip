@@ -6,7 +6,8 @@
 // but without its float32 overflow and without exp/log on
 // the level-to-level critical path.  Arc records stream once per sweep from HBM in
 // level order; per-state sums are reduced by 2^k neighbouring lanes with wave64
-// shuffles.  No MFMA: this is a sparse gather/reduce.
+// shuffles.  The sweeps use no MFMA: they are sparse gather/reduce work; the neuralised
+// beta sweep (neural_kernels.h) has one dense product per state and runs it on float32 MFMA.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
