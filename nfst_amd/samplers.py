@@ -77,3 +77,61 @@ class Sampler:
         idx = torch.nonzero(all_pad)
         stop = int(idx[0]) if idx.numel() > 0 else sequences.shape[1] - 1
         return packed[:, : stop + 1].contiguous()
+
+
+class ProposalSampler(Sampler):
+    """``Sampler.stateful_sample`` for a *learned* proposal (samplers.py:182-335).  The network
+    stays outside: ``score_fn(hx, inp) -> (new_hx, logits [N, V])`` is the reference's recurrent
+    cell + output layer (``left_to_right_score`` without its masks).  Everything on the lattice
+    side of a step -- emission and bos/pad/eos legality masks, the optional next-state value
+    gather (``use_beta``, scorers.py:581-593), temperature, the categorical draw or the forced
+    symbol, its log probability and the state advance -- is one ``nfst_proposal_step`` launch."""
+
+    def __init__(self, model: LatticeScorer, score_fn):
+        super().__init__(model)
+        self.score_fn = score_fn
+
+    def stateful_sample(self, batch_size: int, to_evaluate: Optional[torch.Tensor] = None, hx=None,
+                        temperature: float = 1.0, values: Optional[torch.Tensor] = None,
+                        uniforms: Optional[torch.Tensor] = None, return_zs: bool = False):
+        """``(log_q [N], samples [N, T], hx)``, or ``(log_q, hx)`` when ``to_evaluate`` is given
+        (``(log_q, zs, hx)`` with ``return_zs``), as samplers.py:322-335.  ``uniforms`` [T, N]
+        replace the generator (tests); ``values`` is row-indexed like ``compute_log_beta``."""
+        m = self.model
+        lat = m._lat()
+        dev = lat.device
+        assert batch_size == lat.n_lattices * m.k  # samplers.py:146-150
+        evaluate_only = to_evaluate is not None
+        if evaluate_only:
+            assert int(to_evaluate.shape[0]) == batch_size
+            pad_col = torch.full((batch_size, 1), m.__pad__, dtype=torch.int64, device=dev)
+            padded = torch.cat([to_evaluate.to(device=dev, dtype=torch.int64), pad_col], dim=1)  # samplers.py:208-218
+        inp = torch.full((batch_size,), m.__bos__, dtype=torch.int64, device=dev)
+        # the implicit bos is consumed first (scorers.py:230-231, metadata "state" after inp0 = bos)
+        state = ops.step(lat, torch.zeros(batch_size, dtype=torch.int64, device=dev), inp, k=m.k)
+        log_q = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        zs = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        prefixes = []
+        hard_cut = True
+        for timestep in range(m.max_length + 1):  # + 1 for the additional padding at the end
+            if evaluate_only and timestep >= padded.shape[1]:
+                break
+            hx, logits = self.score_fn(hx, inp)
+            r = ops.proposal_step(lat, state, logits, k=m.k, inp=inp, values=values, pad=m.__pad__, bos=m.__bos__,
+                                  eos=m.__eos__, has_to_end=(timestep + 1) > m.max_length, temperature=temperature,
+                                  uniforms=None if (evaluate_only or uniforms is None) else uniforms[timestep],
+                                  forced=padded[:, timestep] if evaluate_only else None)
+            log_q = log_q + r.logq
+            zs = zs + r.logz
+            prefixes.append(r.symbol)
+            state, inp = r.next_state, r.symbol
+            if self.all_reached_eos(r.symbol):
+                hard_cut = False
+                break
+        if hard_cut and not evaluate_only:
+            raise Exception("ran out of length budget! This should't be possible though.")  # samplers.py:299-302
+        if evaluate_only:
+            return (log_q, zs, hx) if return_zs else (log_q, hx)
+        prefixes.pop(-1)  # the trailing all-pad column (samplers.py:304-307)
+        samples = torch.stack(prefixes, dim=1) if prefixes else torch.empty(batch_size, 0, dtype=torch.int64, device=dev)
+        return log_q, samples, hx

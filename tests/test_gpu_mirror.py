@@ -159,3 +159,48 @@ def test_neural_beta_scorer_matches_reference(dev, golden_dir):
     np.testing.assert_allclose(beta[0], c["beta_per_sample"], rtol=5e-5)
     _, bhat = sc.compute_beta_hat()
     assert bhat.shape == (3, tr.shape[0], H) and float(bhat.abs().max()) <= 1.0
+
+
+def test_proposal_sampler_replays_reference_sampler(dev, golden_dir):
+    """ProposalSampler.stateful_sample (one fused launch per step) with the FSAMaskScorer proposal
+    (uniform logits): forced along the reference sampler's own samples it returns the reference's
+    log q; sampling freely, every sample is an accepting path whose log q is -sum log(out-degree)."""
+    from nfst_amd.samplers import ProposalSampler
+    from nfst_amd import ops
+    d = load(golden_dir, "sampler")
+    K, max_length = int(d["K"]), int(d["max_length"])
+    B, _, V = d["emission"].shape
+    sc = LatticeScorer(V, pad=PAD, bos=BOS, eos=EOS, max_length=max_length).to(dev)
+    steps = []
+
+    def score_fn(hx, inp):
+        steps.append(1)
+        return hx, torch.zeros(inp.shape[0], V, device=dev)
+
+    sp = ProposalSampler(sc, score_fn)
+    sp.set_masks(transition=torch.from_numpy(d["transition"]), emission=torch.from_numpy(d["emission"]))
+    sp.set_k(K)
+    N = B * K
+    log_q, hx = sp.stateful_sample(N, to_evaluate=torch.from_numpy(d["samples"]))
+    assert np.max(np.abs(log_q.cpu().numpy() - d["log_q"])) < 1e-5 and hx is None
+    steps.clear()
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand(max_length + 1, N, generator=g)
+    log_q, samples, _ = sp.stateful_sample(N, uniforms=u)
+    assert samples.shape[0] == N and len(steps) == samples.shape[1] + 1
+    arcs = [O.dense_to_arcs(d["emission"][b], d["transition"][b]) for b in range(B)]
+    s_np, q_np = samples.cpu().numpy(), log_q.cpu().numpy()
+    for n in range(N):
+        src, lab, dst = arcs[n // K][:3]
+        state, ref = int(dst[(src == 0) & (lab == BOS)][0]), 0.0
+        for t in range(s_np.shape[1]):
+            out = (src == state) & (dst != state)
+            if s_np[n, t] == PAD:
+                assert not out.any()  # only in the sink
+                continue
+            legal = out & (lab == s_np[n, t])
+            assert legal.sum() == 1
+            ref -= np.log(out.sum())
+            state = int(dst[legal][0])
+        assert state == d["transition"].shape[1] - 1 or not ((src == state) & (dst != state)).any()
+        assert abs(q_np[n] - ref) < 1e-5
