@@ -165,15 +165,21 @@ def main():
 
     state = {"out": None, "i": 0}
     # sum_b log Z[b] comes out of the kernel itself (atomic adds into one of three rotating slots):
-    # the loss of a step needs no reduction kernel
-    total = torch.zeros(3, dtype=torch.float64, device=dev)
-    fused = args.mode != "bwd" and not args.torch_sum
+    # the loss of a step needs no reduction kernel.  TRIPLES slot triples take turns, so a step's
+    # slot is cleared only 2 * TRIPLES steps later: its all-reduce over ranks has that long to
+    # finish and no launch ever queues behind a collective.
+    TRIPLES = 4
+    total = torch.zeros(3 * TRIPLES, dtype=torch.float64, device=dev)
+    fused = args.mode != "bwd" and not args.torch_sum and not args.graph  # a captured launch has one fixed slot
+
+    def slot_of(i):
+        return i % TRIPLES, (i // TRIPLES) % 3
 
     def run():
         # outputs are allocated by the first call and overwritten afterwards (steady state)
-        slot = state["i"] % 3
+        j, slot = slot_of(state["i"])
         state["i"] += 1
-        kw = dict(total=total, total_slot=slot) if fused else {}
+        kw = dict(total=total[3 * j:3 * j + 3], total_slot=slot) if fused else {}
         if args.mode == "fb":
             state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=True, want_posterior=True, out=state["out"], **kw)
         elif args.mode == "fb_sweeps_only":
@@ -182,18 +188,20 @@ def main():
             return ops.backward(lat, theta, want_logbeta=False)
         return state["out"]
 
-    pending = {"work": None}
+    import collections
+    pending = collections.deque()
 
     def reduce_loss(r):
-        """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously: the collective
-        of step t overlaps the sweep of step t+1; at most one is in flight (its slot of `total` is
-        cleared two launches later)"""
-        slot = (state["i"] - 1) % 3
-        loss = total[slot:slot + 1] if fused else r.logz64.sum()
+        """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously and in place, in
+        the slot the kernel left it in: the collectives of the last steps overlap the sweeps of the
+        next ones; the oldest is waited for (long finished) before its slot comes up for clearing"""
+        j, slot = slot_of(state["i"] - 1)
+        loss = total[3 * j + slot:3 * j + slot + 1] if fused else r.logz64.sum()
         if world > 1:
-            if pending["work"] is not None:
-                pending["work"].wait()
-            loss, pending["work"] = all_reduce_loss(loss, async_op=True, inplace=fused)  # in the slot itself
+            while len(pending) >= (2 * TRIPLES - 2 if fused else 1):
+                pending.popleft().wait()
+            loss, work = all_reduce_loss(loss, async_op=True, inplace=fused)
+            pending.append(work)
         return loss
 
     # --graph: a step is launched by replaying a HIP graph of the forward-backward kernel (the
@@ -246,8 +254,8 @@ def main():
         if timed:
             ev[i // every][1].record()
         loss = reduce_loss(r)
-    if pending["work"] is not None:
-        pending["work"].wait()
+    while pending:
+        pending.popleft().wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
