@@ -329,13 +329,19 @@ int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int3
   if (!scores || !marks || !out || n <= 0 || t <= 0 || vocab <= 0 || !(temp > 0.0f)) return NFST_ERR_ARG;
   if (!(smoothing >= 0.0f && smoothing < 1.0f)) return NFST_ERR_ARG;  // scorers.py:1514
   if (n > 0x7fffffffll) return NFST_ERR_LIMIT;
-#define NFST_LAUNCH_PLP(NV, RB)                                                                         \
-  hipLaunchKernelGGL((k_path_logprob_v4<NV, RB>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
-                     scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,   \
+#define NFST_LAUNCH_PLP(NV, RB, L)                                                                         \
+  hipLaunchKernelGGL((k_path_logprob_v4<NV, RB, L>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
+                     scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,      \
                      temp, (int)normalize, smoothing, out)
-  if (vocab % 4 == 0 && vocab <= 256 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(1, 8);
-  else if (vocab % 4 == 0 && vocab <= 512 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(2, 4);
-  else if (vocab % 4 == 0 && vocab <= 1024 && ((uintptr_t)scores & 15) == 0) NFST_LAUNCH_PLP(4, 2);
+  // 16-byte lane slots a row takes: the variant with the fewest that still holds V / 4 of them
+  const bool v4 = vocab % 4 == 0 && ((uintptr_t)scores & 15) == 0;
+  const int f4 = vocab / 4;
+  if (v4 && f4 <= 32) NFST_LAUNCH_PLP(1, 8, 32);
+  else if (v4 && f4 <= 64) NFST_LAUNCH_PLP(1, 8, 64);
+  else if (v4 && f4 <= 96) NFST_LAUNCH_PLP(3, 4, 32);
+  else if (v4 && f4 <= 128) NFST_LAUNCH_PLP(2, 4, 64);
+  else if (v4 && f4 <= 160) NFST_LAUNCH_PLP(5, 2, 32);
+  else if (v4 && f4 <= 256) NFST_LAUNCH_PLP(4, 2, 64);
   else
     hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
                        (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,

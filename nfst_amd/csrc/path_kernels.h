@@ -455,15 +455,41 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Streaming version for V % 4 == 0, V <= 1024: every wave keeps RB rows in registers
 // (16-byte loads, RB * NV of them in flight per lane -- the kernel is HBM-bound and would be
 // latency-bound with one row at a time), two-pass softmax per row (max, then sum of exp).
-template <int NV, int RB>
+// L = 64: one row per wave; L = 32: one row per half wave (two rows side by side), which wastes
+// fewer of the 16-byte lane slots when V / 4 is just above a multiple of 32 (V = 300: 75 of 96
+// slots instead of 75 of 128) -- the kernel's bandwidth follows the slot use.
+template <int L>
+__device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  if (L == 64) return fmaxf(fmaxf(a, b), fmaxf(c, d));
+  return (threadIdx.x & 32) ? fmaxf(c, d) : fmaxf(a, b);
+}
+template <int L>
+__device__ __forceinline__ float row_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
+  if (L == 64) return (a + b) + (c + d);
+  return (threadIdx.x & 32) ? (c + d) : (a + b);
+}
+
+template <int NV, int RB, int L>
 __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
                                                          const int64_t *__restrict__ marks, int T, int V,
                                                          int pad, int bos, int eos, int max_length,
                                                          float temp, int normalize, float smoothing,
                                                          float *out) {
   __shared__ float part[4];
+  constexpr int HR = 64 / L;  // rows side by side in a wave
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ll = lane & (L - 1), hsel = lane / L;
   const int64_t *mk = marks + n * T;
   const float rtemp = 1.0f / temp;
   // Row-level legality (scorers.py:59-83) only depends on three row flags; which of this lane's
@@ -474,7 +500,7 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
   for (int c = 0; c < NV; ++c)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int col = (c * 64 + lane) * 4 + k;
+      const int col = (c * L + ll) * 4 + k;
       const uint32_t bit = 1u << (c * 4 + k);
       const bool oob = col >= V;
       if (oob || col == bos || col == pad) m_norm |= bit;
@@ -482,17 +508,17 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
       if (oob || col == bos || col == pad || col != eos) m_force |= bit;
     }
   float acc = 0.0f;
-  for (int t0 = wave * RB; t0 < T; t0 += 4 * RB) {
+  for (int t0 = wave * RB * HR; t0 < T; t0 += 4 * RB * HR) {
     float4 v[RB][NV];
     int lab[RB], prev[RB];
     float lraw[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const int t = min(t0 + r, T - 1);  // clamped: rows past the end are loaded but not used
+      const int t = min(t0 + r * HR + hsel, T - 1);  // clamped: rows past the end are loaded but not used
       const float4 *row = reinterpret_cast<const float4 *>(scores + ((size_t)n * T + t) * V);
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
-        const int q = c * 64 + lane;
+        const int q = c * L + ll;
         v[r][c] = (4 * q < V) ? row[q] : make_float4(kNegInf, kNegInf, kNegInf, kNegInf);
       }
       lab[r] = (int)mk[t];
@@ -500,11 +526,12 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r)  // the realised marks' scores: all RB gathers in flight together (L2 hits)
-      lraw[r] = scores[((size_t)n * T + min(t0 + r, T - 1)) * V + lab[r]];
+      lraw[r] = scores[((size_t)n * T + min(t0 + r * HR + hsel, T - 1)) * V + lab[r]];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const int t = t0 + r;
-      if (t >= T) break;
+      if (t0 + r * HR >= T) break;  // wave-uniform: no row of this slot exists
+      const int t = min(t0 + r * HR + hsel, T - 1);
+      const bool valid = t0 + r * HR + hsel < T;  // the second half's row may be past the end
       float sel;
       const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
       const float lx = ((lab[r] == pad ? 0.0f : lraw[r]) + lmsk) / temp + lmsk;
@@ -528,7 +555,7 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
         }
         float lse = 0.0f;
         if (normalize) {
-          mx = wave_max(mx);
+          mx = row_max<L>(mx);
           float sm = 0.0f;
 #pragma unroll
           for (int c = 0; c < NV; ++c) {
@@ -536,7 +563,7 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
 #pragma unroll
             for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);  // masked / padding columns: exp(-inf) = 0
           }
-          sm = wave_sum(sm);
+          sm = row_sum<L>(sm);
           lse = mx + logf(sm);
           sel = lx - lse;  // an all -inf row gives NaN, like the reference
         }
@@ -551,8 +578,8 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
             for (int k = 0; k < 4; ++k)
               if (e[k] > kNegInf) { sx += e[k]; cnt += 1.0f; }
           }
-          sx = wave_sum(sx);
-          cnt = wave_sum(cnt);
+          sx = row_sum<L>(sx);
+          cnt = row_sum<L>(cnt);
           const float own = fminf(fmaxf(sel, -10e8f), 10e8f);
           float rest = sx - cnt * lse;  // sum of the legal marks' values ...
           float others = cnt;
@@ -560,9 +587,11 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
           sel = (1.0f - smoothing) * own + (others > 0.0f ? (smoothing / (cnt - 1.0f)) * rest : 0.0f);
         }
       }
-      acc += sel * (lab[r] != pad ? 1.0f : 0.0f);
+      acc += (valid && lab[r] != pad) ? sel : 0.0f;
     }
   }
+  // every lane of a row's lanes holds the same acc
+  if (HR == 2) acc += read_lane_f(acc, 32);
   if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];

@@ -352,9 +352,11 @@ def test_baseline_batch_properties_and_oracle(dev):
     assert torch.equal(r.posterior, r2.posterior) and torch.equal(r.logz64, r2.logz64)
 
 
-@pytest.mark.parametrize("V,T", [(300, 37), (1000, 11), (301, 9), (64, 300)])
+@pytest.mark.parametrize("V,T", [(300, 37), (1000, 11), (301, 9), (64, 300), (100, 33), (128, 16), (256, 19), (384, 40),
+                                 (500, 10), (600, 21), (640, 7), (644, 9)])
 def test_path_logprob_matches_oracle_all_variants(dev, V, T):
-    """16-byte streaming variants (V % 4 == 0, V <= 1024) and the scalar fallback."""
+    """16-byte streaming variants (V % 4 == 0, V <= 1024: one row per wave or per half wave, 1 to 5
+    16-byte slots per lane; row counts that leave the last slot half empty) and the scalar fallback."""
     rng = np.random.default_rng(V)
     N = 5
     seqs = np.full((N, T), PAD, dtype=np.int64)
