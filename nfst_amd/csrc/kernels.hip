@@ -333,15 +333,25 @@ int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int3
   hipLaunchKernelGGL((k_path_logprob_v4<NV, RB, L>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
                      scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,      \
                      temp, (int)normalize, smoothing, out)
-  // 16-byte lane slots a row takes: the variant with the fewest that still holds V / 4 of them
-  const bool v4 = vocab % 4 == 0 && ((uintptr_t)scores & 15) == 0;
-  const int f4 = vocab / 4;
-  if (v4 && f4 <= 32) NFST_LAUNCH_PLP(1, 8, 32);
-  else if (v4 && f4 <= 64) NFST_LAUNCH_PLP(1, 8, 64);
-  else if (v4 && f4 <= 96) NFST_LAUNCH_PLP(3, 4, 32);
-  else if (v4 && f4 <= 128) NFST_LAUNCH_PLP(2, 4, 64);
-  else if (v4 && f4 <= 160) NFST_LAUNCH_PLP(5, 2, 32);
-  else if (v4 && f4 <= 256) NFST_LAUNCH_PLP(4, 2, 64);
+  // A row lies on a quarter wave (up to 128 slots of 16 bytes, 8 per lane) or a half wave, four or
+  // two rows side by side: the per-row instructions (two reductions, masks) are shared by the rows
+  // of a wave, and the slots a row wastes are at most 15 / 31.
+  const bool v4 = vocab % 4 == 0 && ((uintptr_t)scores & 15) == 0 && vocab <= 1024;
+  const int f4 = vocab / 4, u = f4 <= 128 ? (f4 + 15) / 16 : 8 + (f4 + 31) / 32;
+  if (v4) switch (u) {
+    case 1: NFST_LAUNCH_PLP(1, 8, 16); break;
+    case 2: NFST_LAUNCH_PLP(2, 4, 16); break;
+    case 3: NFST_LAUNCH_PLP(3, 4, 16); break;
+    case 4: NFST_LAUNCH_PLP(4, 2, 16); break;
+    case 5: NFST_LAUNCH_PLP(5, 2, 16); break;
+    case 6: NFST_LAUNCH_PLP(6, 2, 16); break;
+    case 7: NFST_LAUNCH_PLP(7, 1, 16); break;
+    case 8: NFST_LAUNCH_PLP(8, 1, 16); break;
+    case 13: NFST_LAUNCH_PLP(5, 2, 32); break;  // 129 .. 160 slots
+    case 14: NFST_LAUNCH_PLP(6, 2, 32); break;
+    case 15: NFST_LAUNCH_PLP(7, 1, 32); break;
+    default: NFST_LAUNCH_PLP(8, 1, 32); break;  // 16: up to 256 slots
+  }
   else
     hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
                        (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,

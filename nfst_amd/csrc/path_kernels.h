@@ -455,15 +455,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Streaming version for V % 4 == 0, V <= 1024: every wave keeps RB rows in registers
 // (16-byte loads, RB * NV of them in flight per lane -- the kernel is HBM-bound and would be
 // latency-bound with one row at a time), two-pass softmax per row (max, then sum of exp).
-// L = 64: one row per wave; L = 32: one row per half wave (two rows side by side), which wastes
-// fewer of the 16-byte lane slots when V / 4 is just above a multiple of 32 (V = 300: 75 of 96
-// slots instead of 75 of 128) -- the kernel's bandwidth follows the slot use.
+// A row lies on L lanes: a quarter wave (L = 16, four rows side by side), a half wave (32) or a
+// whole wave (64).  Narrow rows waste fewer of the 16-byte lane slots (V = 300: 75 of 80 with
+// L = 16 and five slots per lane, 75 of 128 with a wave per row) and share the per-row
+// instructions (reductions, masks) among the rows of a wave; the launcher uses 16 up to V = 512
+// and 32 above.  Measured at V = 300: 3.1 TB/s with L = 64, 4.2 with L = 32, 5.3 with L = 16.
 template <int L>
 __device__ __forceinline__ float row_max(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));
   v = fmaxf(v, dpp_f<0x4E>(v));
   v = fmaxf(v, dpp_f<0x141>(v));
   v = fmaxf(v, dpp_f<0x140>(v));
+  if (L == 16) return v;  // a DPP row: every lane holds its row's result
   const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
   if (L == 64) return fmaxf(fmaxf(a, b), fmaxf(c, d));
   return (threadIdx.x & 32) ? fmaxf(c, d) : fmaxf(a, b);
@@ -474,6 +477,7 @@ __device__ __forceinline__ float row_sum(float v) {
   v += dpp_f<0x4E>(v);
   v += dpp_f<0x141>(v);
   v += dpp_f<0x140>(v);
+  if (L == 16) return v;
   const float a = read_lane_f(v, 0), b = read_lane_f(v, 16), c = read_lane_f(v, 32), d = read_lane_f(v, 48);
   if (L == 64) return (a + b) + (c + d);
   return (threadIdx.x & 32) ? (c + d) : (a + b);
@@ -592,6 +596,7 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
   }
   // every lane of a row's lanes holds the same acc
   if (HR == 2) acc += read_lane_f(acc, 32);
+  if (HR == 4) acc = (read_lane_f(acc, 0) + read_lane_f(acc, 16)) + (read_lane_f(acc, 32) + read_lane_f(acc, 48));
   if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];

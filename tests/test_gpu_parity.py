@@ -353,9 +353,10 @@ def test_baseline_batch_properties_and_oracle(dev):
 
 
 @pytest.mark.parametrize("V,T", [(300, 37), (1000, 11), (301, 9), (64, 300), (100, 33), (128, 16), (256, 19), (384, 40),
-                                 (500, 10), (600, 21), (640, 7), (644, 9)])
+                                 (500, 10), (600, 21), (640, 7), (644, 9), (36, 9), (180, 23), (332, 18), (440, 13),
+                                 (700, 9), (900, 5), (1024, 6), (1028, 4)])
 def test_path_logprob_matches_oracle_all_variants(dev, V, T):
-    """16-byte streaming variants (V % 4 == 0, V <= 1024: one row per wave or per half wave, 1 to 5
+    """16-byte streaming variants (V % 4 == 0, V <= 1024: one row per wave, half wave or quarter wave, 1 to 7
     16-byte slots per lane; row counts that leave the last slot half empty) and the scalar fallback."""
     rng = np.random.default_rng(V)
     N = 5
