@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <cmath>
+#include <type_traits>
 
 #include "nfst_hip.h"
 

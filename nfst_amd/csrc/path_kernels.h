@@ -7,8 +7,11 @@
 // -- canonical arc and next state -- in LDS; the program is read straight from global
 // memory), then lane 0 walks the best path inside LDS.  Ties keep the arc with the smallest
 // canonical id, i.e. the smallest label.
-__device__ __forceinline__ void vit_take(float &bv, int &ba, int &bn, float ov, int oa, int on) {
-  if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; bn = on; }  // bn: the arc's other end
+__device__ __forceinline__ void vit_take(float &bv, int &ba, int &bn, float ov, int oa, int on, bool allowed = true) {
+  const bool t = allowed & ((ov > bv) | ((ov == bv) & (oa < ba)));  // bitwise on purpose: selects, no branches
+  bv = t ? ov : bv;
+  ba = t ? oa : ba;
+  bn = t ? on : bn;  // the arc's other end
 }
 
 // Wave 0 runs the program; waves 1 .. 3 run ahead of it and pull the tiles it will read
@@ -62,42 +65,49 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
     }
     if (sink_f == 1.2345e-33f && sink_i == 0x12345678) best[b] = 0.0f;  // keeps the loads alive, never true
   } else {
-  // the words of tile T+1 are loaded while tile T is computed
-  struct VitTile { uint32_t ctl; int cas[4]; uint32_t rcs[4]; };
+  // The words of tile T+1 are loaded while tile T is computed: loads only, nothing is unpacked
+  // before the tile's turn (a use would make the wave wait for the L2 round trip right away), and
+  // the format is a compile-time constant of the loop (a branch around loads ends in a full wait).
+  struct VitTile { uint4 x; uint32_t w[4]; int cas[4]; };
+  auto sweep = [&](auto compact_tag, auto extra_tag) {
+  constexpr bool kCompact = decltype(compact_tag)::value, kExtra = decltype(extra_tag)::value;
   auto load_tile = [&](int T, VitTile &t) {
-    if (F == 8) {  // compact tile: control word + four 24-bit records per lane
-      const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
-      t.ctl = x.x;
-      const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+    if (kCompact) {  // control word + four 24-bit records per lane
+      t.x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        t.cas[j] = perm[(size_t)T * 256 + lane * 4 + j];
-        t.rcs[j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);  // as a 32-bit record
-      }
+      for (int j = 0; j < 4; ++j) t.cas[j] = perm[(size_t)T * 256 + lane * 4 + j];
       return;
     }
-    t.ctl = prog[(size_t)T * ST + lane];
+    t.x.x = prog[(size_t)T * ST + lane];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int jj = min(j, U - 1);
       t.cas[j] = perm[(size_t)T * 64 * U + lane * U + jj];
-      t.rcs[j] = prog[(size_t)T * ST + 64 + lane * U + jj];
+      t.w[j] = prog[(size_t)T * ST + 64 + lane * U + jj];
     }
   };
-  VitTile cur, nxt;
-  if (m.bwd_tiles > 0) load_tile(0, cur);
-  for (int T = 0; T < m.bwd_tiles; ++T) {
+  // iteration T: `cur` = tile T, `nxt` receives tile T+1
+  auto step = [&](int T, const VitTile &cur, VitTile &nxt) {
     load_tile(min(T + 1, m.bwd_tiles - 1), nxt);
-    const uint32_t ctl = cur.ctl;
+    const uint32_t ctl = cur.x.x;
     int cas[4];
     uint32_t rcs[4];
     float xs[4];
+    if (kCompact) {
+      const uint4 x = cur.x;
+      const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cas[j] = (j < U) ? cur.cas[j] : -1; rcs[j] = cur.rcs[j]; }
+      for (int j = 0; j < 4; ++j) rcs[j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);  // as a 32-bit record
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rcs[j] = cur.w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cas[j] = (j < U) ? cur.cas[j] : -1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       xs[j] = 0.0f;
-      if (cas[j] >= 0) {
+      if (kExtra && cas[j] >= 0) {  // (a loop without extras has no load but the prefetch)
         if (arc_w) xs[j] += arc_w[cas[j]];
         if (sc.arc_scores) xs[j] += sc.arc_scores[cas[j]];
       }
@@ -106,11 +116,24 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
     int ba = kNone, bn = -1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      // straight-line: every slot reads its label score and operand value (an empty slot has
+      // operand 0 and the null label, whose "score" is the word behind the table -- never used)
       const int other = (int)((rcs[j] & 0xffffu) >> 3);
-      if (cas[j] >= 0) vit_take(bv, ba, bn, tl[rcs[j] >> 16] + xs[j] + v[other], cas[j], other);
-      // a unit-label record stands for what row `other` holds -- the state's own earlier pieces
-      // (carry) or a scratch row of a partial group: its best arc competes as such
-      else if (j < U && (int)(rcs[j] >> 16) == lat.vocab + 1 && bp[other] >= 0) vit_take(bv, ba, bn, v[other], bp[other], ns[other]);
+      xs[j] += tl[rcs[j] >> 16] + v[other];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vit_take(bv, ba, bn, xs[j], cas[j], (int)((rcs[j] & 0xffffu) >> 3), cas[j] >= 0);
+    // a unit-label record stands for what row `other` holds -- the state's own earlier pieces
+    // (carry) or a scratch row of a partial group: its best arc competes as such.  Rare.
+    bool unit[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unit[j] = (j < U) & (cas[j] < 0) & ((int)(rcs[j] >> 16) == lat.vocab + 1);
+    if (__builtin_amdgcn_ballot_w64(unit[0] | unit[1] | unit[2] | unit[3])) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int other = (int)((rcs[j] & 0xffffu) >> 3);
+        if (unit[j] && bp[other] >= 0) vit_take(bv, ba, bn, v[other], bp[other], ns[other]);
+      }
     }
     const int gl = (int)((ctl >> 20) & 7u);
     const int gmax = (int)((__builtin_amdgcn_readfirstlane(ctl) >> 23) & 7u);
@@ -120,7 +143,7 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
     if (gmax > ST) {                                                        \
       const float ov = FV(bv);                                              \
       const int oa = FI(ba), on = FI(bn);                                   \
-      if (gl > ST) vit_take(bv, ba, bn, ov, oa, on);                        \
+      vit_take(bv, ba, bn, ov, oa, on, gl > ST);                            \
     }
 #define NFST_SHFL16(x) __shfl_xor(x, 16)
 #define NFST_SHFL32(x) __shfl_xor(x, 32)
@@ -142,8 +165,20 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
     // LDS accesses of one wave execute in order: the next tile's loads see these stores
     asm volatile("" ::: "memory");
     if ((T & 3) == 3) lds_flag_store(progress, T);
-    cur = nxt;
+  };
+  VitTile ta, tb;
+  if (m.bwd_tiles > 0) load_tile(0, ta);
+  // two iterations per trip so that the register roles alternate without copies (a copy of
+  // registers with a load in flight would wait for it)
+  for (int T = 0; T < m.bwd_tiles; T += 2) {
+    step(T, ta, tb);
+    if (T + 1 >= m.bwd_tiles) break;
+    step(T + 1, tb, ta);
   }
+  };
+  const bool extras = arc_w != nullptr || sc.arc_scores != nullptr;
+  if (F == 8) { if (extras) sweep(std::true_type{}, std::true_type{}); else sweep(std::true_type{}, std::false_type{}); }
+  else { if (extras) sweep(std::false_type{}, std::true_type{}); else sweep(std::false_type{}, std::false_type{}); }
   }
   // lane 0 walks the back pointers inside LDS (arc ids go to the list `pa`, which reuses the
   // value array); all threads then write the labels
