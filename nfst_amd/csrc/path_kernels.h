@@ -290,9 +290,8 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
     const int es = __float_as_int(bs.y);
     float cum_base = 0.0f, sc_ch = 0.0f, sc_last = 0.0f;
     int chosen = -1, last = -1, d_ch = 0, d_last = 0;
-    bool more = active;
-    for (int c = a0; __any(more); c += 16) {
-      more = more && c < a1 && chosen < 0;
+    bool more = active & (a0 < a1);
+    for (int c = a0; __any(more); c += 16) {  // `more` is updated at the end: no empty last round
       const int a = c + r;
       float p = 0.0f, x = 0.0f;
       int d = 0;
@@ -320,13 +319,16 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
       const int f = hit ? __builtin_ctz(hit) : 0, l = pos ? 31 - __builtin_clz(pos) : 0;
       const float x_f = __shfl(x, f, 16), x_l = __shfl(x, l, 16), c_end = __shfl(cum, 15, 16);
       const int d_f = __shfl(d, f, 16), d_l = __shfl(d, l, 16);
-      if (more) {
-        if (hit) { chosen = c + f; sc_ch = x_f; d_ch = d_f; }
-        else {
-          cum_base = c_end;
-          if (pos) { last = c + l; sc_last = x_l; d_last = d_l; }
-        }
-      }
+      // selects, no branches (hipcc turns && / || and small ifs into execution-mask branches)
+      const bool take = more & (hit != 0), keep = more & (hit == 0), seen = keep & (pos != 0);
+      chosen = take ? c + f : chosen;
+      sc_ch = take ? x_f : sc_ch;
+      d_ch = take ? d_f : d_ch;
+      cum_base = keep ? c_end : cum_base;
+      last = seen ? c + l : last;
+      sc_last = seen ? x_l : sc_last;
+      d_last = seen ? d_l : d_last;
+      more = more & (c + 16 < a1) & (chosen < 0);
     }
     if (active) {
       if (chosen < 0) { chosen = last; sc_ch = sc_last; d_ch = d_last; }
