@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
     ap.add_argument("--graph", action="store_true", help="replay a HIP graph of the step instead of launching from Python "
                     "(measured slower on ROCm 7.2: 67.8 vs 59.2 us per step)")
-    ap.add_argument("--event-every", type=int, default=8, help="HIP events around every n-th timed launch")
+    ap.add_argument("--event-every", type=int, default=8, help="HIP events around runs of n back-to-back launches")
     ap.add_argument("--torch-sum", action="store_true", help="reduce the loss with torch.sum instead of the kernel's fused total")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
@@ -241,18 +241,20 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    # kernel duration: HIP events around every `every`-th launch of the timed region (events are
-    # extra commands between back-to-back launches: bracketing each one costs ~1 us per step)
-    every = max(1, args.event_every)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(0, args.steps, every)]
+    # kernel duration: HIP events on the launch stream around every run of `span` back-to-back
+    # launches of the timed region, divided by span (nothing else runs on that stream, so this is
+    # an upper bound of the average kernel duration; an event pair around every single launch adds
+    # ~2.5 us of command gaps to each and reads 5 % high against rocprofv3's kernel trace)
+    span = max(1, min(args.event_every, args.steps))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps // span)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        timed = i % every == 0
-        if timed:
-            ev[i // every][0].record()
+        g, k = divmod(i, span)
+        if k == 0 and g < len(ev):
+            ev[g][0].record()
         r = launch()
-        if timed:
-            ev[i // every][1].record()
+        if k == span - 1 and g < len(ev):
+            ev[g][1].record()
         loss = reduce_loss(r)
     while pending:
         pending.popleft().wait()
@@ -261,7 +263,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / span
     total_arcs = arcs
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
