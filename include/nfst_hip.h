@@ -238,8 +238,8 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
  * Exact posterior path sampling: K walks per lattice from state 0; at state s
  * arc a is taken with probability exp(score[a] + beta[dst] - beta[s]), chosen by
  * inverse CDF over the state's arcs in label order from uniforms [B, K, max_len]
- * (device float32 in [0,1)); if uniforms is NULL a Philox4x32-10 stream keyed by
- * (seed, walk, step) is used.  paths [B, K, max_len] labels padded with `pad`,
+ * (device float32 in [0,1)); if uniforms is NULL a Philox4x32-10 stream is used
+ * (key = seed, counter = (walk, step / 4): one output word per step).  paths [B, K, max_len] labels padded with `pad`,
  * path_arcs (optional) canonical arc ids, lengths [B, K], logq [B, K] =
  * path score - log Z.  status (device int32, one word, zeroed by the caller)
  * becomes NFST_ERR_LENGTH if a walk does not reach the sink within max_len.

@@ -215,8 +215,9 @@ __device__ __forceinline__ uint32_t mulhilo(uint32_t a, uint32_t b, uint32_t *hi
   return (uint32_t)p;
 }
 // Philox4x32-10, counter (walk, step, 0, 0), key from seed; first output word -> [0,1)
-__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t walk, uint32_t step) {
-  uint32_t c0 = walk, c1 = step, c2 = 0, c3 = 0;
+// Philox4x32-10 block keyed by the seed, counter (walk, step / 4): four uniforms, one per step
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint32_t walk, uint32_t block, float (&u)[4]) {
+  uint32_t c0 = walk, c1 = block, c2 = 0, c3 = 0;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   for (int i = 0; i < 10; ++i) {
     uint32_t hi0, hi1;
@@ -225,7 +226,10 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t walk, ui
     c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+  u[0] = (float)(c0 >> 8) * (1.0f / 16777216.0f);
+  u[1] = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+  u[2] = (float)(c2 >> 8) * (1.0f / 16777216.0f);
+  u[3] = (float)(c3 >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ float arc_score(const float *theta, const float *arc_w,
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
   int32_t *outa = path_arcs ? path_arcs + walk * max_len : nullptr;
   int s = 0, t = 0;
   float tot = 0.0f;
+  float ublk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   bool ok = true;
   bool active = live;
   while (true) {
@@ -281,7 +286,12 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
     float2 bs = make_float2(1.0f, 0.0f);
     int a0 = 0, a1 = 0;
     if (active) {
-      u = uniforms ? uniforms[walk * max_len + t] : philox_uniform(seed, (uint32_t)walk, (uint32_t)t);
+      if (uniforms) {
+        u = uniforms[walk * max_len + t];
+      } else {  // one Philox block serves four steps
+        if ((t & 3) == 0) philox_uniform4(seed, (uint32_t)walk, (uint32_t)(t >> 2), ublk);
+        u = (t & 3) == 0 ? ublk[0] : ((t & 3) == 1 ? ublk[1] : ((t & 3) == 2 ? ublk[2] : ublk[3]));
+      }
       bs = bl[s];
       a0 = rp[s];
       a1 = rp[s + 1];
