@@ -218,3 +218,10 @@ def test_packed_sidecar_round_trip(tmp_path):
         LatticeBatch.load(side)
     os.utime(side, (os.path.getmtime(names[0]) + 10,) * 2)
     assert io.load_packed(names[0])._h == first[0]._h  # rebuilt
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: compiles (or finds up to date) the HIP library and the oracle and
+    verifies the library against the header's ABI version."""
+    import __graft_entry__ as g
+    g.build()
