@@ -751,6 +751,8 @@ def test_beta_neural_against_oracle(dev, H):
     for opts in all_opts:
         lat = LatticeBatch.from_synth(lats, device=dev, **opts)
         r = _run_neural(lat, p)
+        again = _run_neural(lat, p)  # the phases hand rows over through LDS and L2: no race, no stale line
+        assert torch.equal(r.log_beta, again.log_beta) and torch.equal(r.beta_hat, again.beta_hat)
         lb, bh = r.log_beta.cpu().numpy().astype(np.float64), r.beta_hat.cpu().numpy()
         for b, (l, (logb, bhat)) in enumerate(zip(lats, refs)):
             r0 = int(lat.row_off[b])
