@@ -139,6 +139,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # leave 56 KiB of every CU's LDS free (costs 0.8 % of the step: shallower rings) so that
+        # RCCL's all-reduce kernel can run beside a sweep workgroup instead of taking a whole CU
+        # away from the next launch (a sweep workgroup otherwise owns its CU's LDS)
+        os.environ.setdefault("NFST_LDS_RESERVE_KB", "56")
         import torch.distributed as dist
         # RCCL ("nccl" on ROCm) over xGMI; NFST_BENCH_BACKEND=gloo only to rehearse the multi-rank
         # code path on a box where several ranks must share one GPU
@@ -293,7 +297,8 @@ def main():
                        "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
                        "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()), "host_pack_s": pack_s,
                        "launch": "hip_graph_replay" if use_graph else "python",
-                       "loss_reduction": "fused in the kernel (atomic adds)" if fused else "torch.sum"},
+                       "loss_reduction": "fused in the kernel (atomic adds)" if fused else "torch.sum",
+                       "lds_reserve_kb": int(os.environ.get("NFST_LDS_RESERVE_KB", "0") or 0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,

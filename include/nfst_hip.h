@@ -220,6 +220,9 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
  * lattice's log Z to logz_total[total_slot] (atomic adds: the summation order is not fixed) and
  * clears logz_total[(total_slot + 1) % 3] for the next launch -- the loss of a training step
  * without a reduction kernel; use total_slot = step % 3.
+ * Environment: NFST_LDS_RESERVE_KB=<0..96> (read once per process) makes nfst_backward and
+ * nfst_forward_backward leave that much LDS free on every CU when they run one lattice per CU,
+ * so that a small kernel of another stream (RCCL's all-reduce of the loss) can run beside them.
  */
 int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, float *logalpha,
                           float *logbeta, double *logz64, float *logz32, float *posterior,

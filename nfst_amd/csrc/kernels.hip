@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cmath>
 #include <type_traits>
 
@@ -100,6 +101,19 @@ static int cu_count() {
 //   shared (more lattices than CUs): the decoder loads for itself, shallow staging ring, and
 //          two workgroups share a CU's 160 KiB when the lattices are small enough.
 // A lattice too large for the deep rings runs the shared flavour with the whole CU.
+// NFST_LDS_RESERVE_KB (environment, read once): LDS the one-lattice-per-CU flavour leaves free on
+// every CU, so that a small kernel of another stream -- RCCL's all-reduce of the loss -- finds a CU
+// to run on beside a sweep workgroup instead of waiting for one to retire.  Costs ring depth only.
+static int64_t lds_reserve() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char *e = getenv("NFST_LDS_RESERVE_KB");
+    const long kb = e ? strtol(e, nullptr, 10) : 0;
+    v = (kb > 0 && kb <= 96) ? kb * 1024 : 0;
+  }
+  return v;
+}
+
 struct RingCfg { int R, RS; bool self; };
 static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, RingCfg *c) {
   const int n_rings = fb ? 2 : 1;
@@ -107,7 +121,7 @@ static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, Rin
   auto fixed = [&](int RS) { return fb ? plan.fb_bytes(0, RS, extra) : plan.bwd_bytes(0, RS, extra); };
   auto clampr = [](int64_t r) { return (int)(r > kMaxRing ? kMaxRing : r); };
   if (deep) {
-    const int64_t r = (kMaxLds - fixed(kRawSlotsDeep)) / slot;
+    const int64_t r = (kMaxLds - lds_reserve() - fixed(kRawSlotsDeep)) / slot;
     if (r >= kMinRing) { *c = {clampr(r), kRawSlotsDeep, false}; return true; }
   } else {
     const int64_t r = (kMaxLds / 2 - fixed(kRawSlotsShared)) / slot;
