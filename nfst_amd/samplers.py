@@ -129,7 +129,7 @@ class ProposalSampler(Sampler):
                 hard_cut = False
                 break
         if hard_cut and not evaluate_only:
-            raise Exception("ran out of length budget! This should't be possible though.")  # samplers.py:299-302
+            raise Exception("a sample did not end within max_length + 1 steps")  # the reference raises here too (samplers.py:299-302)
         if evaluate_only:
             return (log_q, zs, hx) if return_zs else (log_q, hx)
         prefixes.pop(-1)  # the trailing all-pad column (samplers.py:304-307)
