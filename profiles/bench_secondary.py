@@ -37,6 +37,9 @@ t = timeit(lambda: ops.step(lat, st, lb, k=64))
 out["step_K64"] = {"ms": t * 1e3, "walkers/s": 256 * 64 / t}
 t = timeit(lambda: ops.emission_mask(lat, st, k=64, inp=lb))
 out["emission_mask_K64"] = {"ms": t * 1e3, "GB/s_written": 256 * 64 * 256 * 4 / t / 1e9}
+sc64 = torch.randn(256 * 64, 256, device=dev); u64 = torch.rand(256 * 64, device=dev)
+t = timeit(lambda: ops.proposal_step(lat, st, sc64, k=64, inp=lb, uniforms=u64))
+out["proposal_step_K64"] = {"ms": t * 1e3, "walkers/s": 256 * 64 / t, "note": "incl. the Python wrapper (4 output allocations)"}
 t = timeit(lambda: ops.gather_label_scores(lat, theta))
 out["gather_label_scores"] = {"ms": t * 1e3, "GB/s": lat.total_arcs * 8 / t / 1e9}
 # neuralised beta: hid_dim of the reference's configs (conf/train/*.yaml: 256) and a small one
