@@ -75,3 +75,46 @@ def collate_packed(examples, device=None):
     from .lattice import LatticeBatch
 
     return LatticeBatch.concat(list(examples), device=device)
+
+
+class DevicePrefetcher:
+    """Yields the packed batches of an iterable on the device, with the host-to-device copy of the
+    next batch running on a side stream while the current one is being used -- the role of the
+    DataLoader's ``pin_memory`` + ``.to(device, non_blocking=True)`` in the reference's trainer
+    (a packed BASELINE batch is ~240 MB: ~5 ms over PCIe, a hundred sweep steps' worth)."""
+
+    def __init__(self, batches, device):
+        import torch
+
+        self.batches = batches
+        self.device = torch.device(device)
+
+    def __iter__(self):
+        import torch
+
+        side = torch.cuda.Stream(self.device)
+
+        def stage(b):
+            pinned = b.pin_memory()
+            with torch.cuda.stream(side):
+                d = pinned.to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return d, ev, pinned  # the pinned copy must outlive the transfer
+
+        it = iter(self.batches)
+        try:
+            nxt = stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = stage(next(it))
+            except StopIteration:
+                nxt = None
+            torch.cuda.current_stream(self.device).wait_event(cur[1])
+            for t in cur[0]._t.values():
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            yield cur[0]

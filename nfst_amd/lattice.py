@@ -223,10 +223,20 @@ class LatticeBatch:
         return out.to(device) if device is not None else out
 
     # ---------------------------------------------------------------- placement
-    def to(self, device) -> "LatticeBatch":
+    def to(self, device, non_blocking: bool = False) -> "LatticeBatch":
         device = torch.device(device)
-        t = {k: (None if v is None else v.to(device)) for k, v in self._t.items()}
-        return LatticeBatch(self._h, t)
+        t = {k: (None if v is None else v.to(device, non_blocking=non_blocking)) for k, v in self._t.items()}
+        out = LatticeBatch.__new__(LatticeBatch)
+        out._h, out._t, out._struct = dict(self._h), t, None
+        out.meta_host = self.meta_host  # shapes and offsets stay on the host: no device round trip
+        return out
+
+    def pin_memory(self) -> "LatticeBatch":
+        """Page-locked host copy: what ``to(device, non_blocking=True)`` needs to be asynchronous."""
+        t = {k: (None if v is None else v.pin_memory()) for k, v in self._t.items()}
+        out = LatticeBatch.__new__(LatticeBatch)
+        out._h, out._t, out._struct, out.meta_host = dict(self._h), t, None, self.meta_host
+        return out
 
     @property
     def device(self) -> torch.device:

@@ -204,3 +204,20 @@ def test_proposal_sampler_replays_reference_sampler(dev, golden_dir):
             state = int(dst[legal][0])
         assert state == d["transition"].shape[1] - 1 or not ((src == state) & (dst != state)).any()
         assert abs(q_np[n] - ref) < 1e-5
+
+
+def test_device_prefetcher_overlaps_copies_and_changes_nothing(dev):
+    """io.DevicePrefetcher: batches arrive on the device through pinned memory and a side stream;
+    results are those of a plain blocking copy."""
+    from nfst_amd import ops
+    from nfst_amd.lattice import LatticeBatch
+    theta = torch.from_numpy(synth.label_scores(3, 64))
+    cpu = [LatticeBatch.from_synth([synth.layered_lattice(500 + 7 * i + j, n_states=120 + 30 * j, avg_degree=5.0, vocab=64,
+                                                           width=4, span=3) for j in range(4)]) for i in range(5)]
+    want = [ops.forward_backward(b.to(dev), theta).logz64.cpu() for b in cpu]
+    got = []
+    for b in io.DevicePrefetcher(cpu, dev):
+        assert b.device.type == "cuda"
+        got.append(ops.forward_backward(b, theta).logz64.cpu())
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    assert list(io.DevicePrefetcher([], dev)) == []
