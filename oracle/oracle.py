@@ -202,20 +202,22 @@ def beta_dense_frontier(transition: np.ndarray, emb, Wx, Wh, W, bias) -> Tuple[n
     return beta, int(it)
 
 
-def beta_neural(n_rows: int, src, label, dst, emb, Wx, Wh, W, bias):
+def beta_neural(n_rows: int, src, label, dst, emb, Wx, Wh, W, bias, arc_w=None):
     """compute_beta_per_sample with its Tree-LSTM-style messages (scorers.py:692-751), restated in
     float64 with beta kept in log space: for every arc (s, l, s') with s' != s
         t = tanh(Wx e(l) + Wh beta_hat(s') + bias),   msg = exp(W . t) * beta(s')       (:732-738)
         beta(s) = sum msg,   beta_hat(s) = sum (msg / beta(s)) t                         (:743-747)
     from beta(sink) = 1, beta_hat(sink) = 0 (:699-701, 720).  Parallel arcs count once each, as in
-    the per-sample loop.  Returns (log beta [n_rows], beta_hat [n_rows, H]); states that do not
-    reach the sink get -inf / 0."""
+    the per-sample loop.  ``arc_w`` (float emission tables, scorers.py:1011-1027; not used by the
+    reference's beta) adds a log weight per arc to W . t.  Returns (log beta [n_rows], beta_hat
+    [n_rows, H]); states that do not reach the sink get -inf / 0."""
     src = np.asarray(src, np.int64); label = np.asarray(label, np.int64); dst = np.asarray(dst, np.int64)
     emb = np.asarray(emb, np.float64); Wx = np.asarray(Wx, np.float64); Wh = np.asarray(Wh, np.float64)
     W = np.asarray(W, np.float64).reshape(-1); bias = np.asarray(bias, np.float64)
     H = emb.shape[1]
     keep = src != dst
-    src, label, dst = src[keep], label[keep], dst[keep]
+    aw = np.zeros(src.shape[0]) if arc_w is None else np.asarray(arc_w, np.float64)
+    src, label, dst, aw = src[keep], label[keep], dst[keep], aw[keep]
     x = emb @ Wx.T + bias  # [V, H]
     out = [[] for _ in range(n_rows)]
     pending = np.zeros(n_rows, np.int64)
@@ -239,7 +241,7 @@ def beta_neural(n_rows: int, src, label, dst, emb, Wx, Wh, W, bias):
             if pending[s] == 0:
                 arcs = out[s]
                 t = np.tanh(x[label[arcs]] + bhat[dst[arcs]] @ Wh.T)  # [n, H]
-                lm = t @ W + logb[dst[arcs]]
+                lm = t @ W + aw[arcs] + logb[dst[arcs]]
                 mx = lm.max()
                 if np.isneginf(mx):
                     continue

@@ -778,3 +778,11 @@ def test_beta_neural_weighted_tables_and_zero_wh(dev):
         cmp_rows(r.log_beta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tol=2e-5)
     with pytest.raises(ValueError):
         ops.backward_neural(lat, torch.zeros(V, H), torch.zeros(H, H), torch.zeros(H + 1, H), torch.zeros(H), torch.zeros(H))
+    # table weights together with the state term
+    p = _neural_params(6, V, H, scale=2.0)
+    r = _run_neural(lat, p)
+    for b, l in enumerate(lats):
+        logb, bhat = O.beta_neural(l.n_rows, l.src, l.label, l.dst, p["emb"], p["Wx"], p["Wh"], p["W"], p["bias"], arc_w=l.weight)
+        r0 = int(lat.row_off[b])
+        cmp_rows(r.log_beta.cpu().numpy()[r0:r0 + l.n_rows], logb, tol=3e-5)
+        assert np.max(np.abs(r.beta_hat.cpu().numpy()[r0:r0 + l.n_rows] - bhat)) <= 3e-5
