@@ -37,8 +37,11 @@
  *   - plain C: pointers and sizes only, no C++/torch types.
  *   - "device" pointers are HIP device memory owned by the caller (the Python
  *     host side passes torch tensors' data_ptr()); "host" pointers are ordinary
- *     memory.  The library allocates device memory nowhere and keeps no global
- *     state; every launch goes to the hipStream_t passed as `stream` (void*).
+ *     memory.  The library allocates device memory nowhere; every launch goes to
+ *     the hipStream_t passed as `stream` (void*) on the calling thread's current
+ *     device.  Its only process state is a mutex-guarded cache, keyed by device,
+ *     of the kernels' dynamic-LDS opt-ins and of the CU count: several devices in
+ *     one process and launches from several host threads are safe.
  *   - every function returns NFST_OK (0) or a negative error code; the message
  *     is available from nfst_strerror().  Kernels are never launched on invalid
  *     shapes: all operands are validated on the host first.

@@ -94,9 +94,18 @@ def _load():
     return l, list(sig)
 
 
+def header_abi_version() -> int:
+    """NFST_ABI_VERSION of include/nfst_hip.h -- the one place the ABI version is written down."""
+    import re
+    with open(os.path.join(os.path.dirname(_HERE), "include", "nfst_hip.h")) as f:
+        return int(re.search(r"#define\s+NFST_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
 lib, EXPORTS = _load()
-if lib.nfst_abi_version() != 3:
-    raise ImportError("libnfst_hip.so ABI version mismatch; rebuild with `python -m nfst_amd.build --force`")
+ABI_VERSION = header_abi_version()
+if lib.nfst_abi_version() != ABI_VERSION:
+    raise ImportError(f"libnfst_hip.so has ABI {lib.nfst_abi_version()}, include/nfst_hip.h says {ABI_VERSION}; "
+                      "rebuild with `python -m nfst_amd.build --force`")
 
 
 def check(code: int, where: str, lattice: int = -1) -> None:

@@ -13,7 +13,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cmath>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "nfst_hip.h"
 
@@ -45,26 +47,47 @@ int hip_status(hipError_t e) { return e == hipSuccess ? NFST_OK : NFST_ERR_HIP; 
 
 constexpr int64_t kMaxLds = 160 * 1024;
 
-// Dynamic LDS above 64 KiB needs a per-kernel opt-in; it is sticky, so it is requested
-// once per kernel and size (hipFuncSetAttribute is slow and not capturable in a graph).
+// Dynamic LDS above 64 KiB needs a per-kernel opt-in; it is sticky per (device, kernel), so it is
+// requested once per device, kernel and size (hipFuncSetAttribute is slow and not capturable in a
+// graph).  The cache is the library's only process state: keyed by the current device and guarded
+// by a mutex, so several devices in one process and launches from several host threads are safe.
+struct LdsSeen { int dev; const void *fn; int64_t bytes; };
+std::mutex g_lds_mutex;
+std::vector<LdsSeen> g_lds_seen;
+
 template <class K>
 int set_lds(K kernel, int64_t bytes) {
   if (bytes > kMaxLds) return NFST_ERR_LIMIT;
   if (bytes <= 64 * 1024) return NFST_OK;
-  static const void *seen_fn[32];
-  static int64_t seen_bytes[32];
-  static int n_seen = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NFST_ERR_HIP;
   const void *fn = reinterpret_cast<const void *>(kernel);
-  for (int i = 0; i < n_seen; ++i)
-    if (seen_fn[i] == fn) {
-      if (seen_bytes[i] >= bytes) return NFST_OK;
+  std::lock_guard<std::mutex> lock(g_lds_mutex);
+  for (LdsSeen &e : g_lds_seen)
+    if (e.dev == dev && e.fn == fn) {
+      if (e.bytes >= bytes) return NFST_OK;
       int rc = hip_status(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      if (rc == NFST_OK) seen_bytes[i] = bytes;
+      if (rc == NFST_OK) e.bytes = bytes;
       return rc;
     }
   int rc = hip_status(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  if (rc == NFST_OK && n_seen < 32) { seen_fn[n_seen] = fn; seen_bytes[n_seen] = bytes; ++n_seen; }
+  if (rc == NFST_OK) g_lds_seen.push_back({dev, fn, bytes});
   return rc;
+}
+
+// number of CUs of the current device (cached per device; 256 on MI355X)
+int cu_count() {
+  static std::mutex mu;
+  static std::vector<int> per_dev;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)per_dev.size() <= dev) per_dev.resize(dev + 1, 0);
+  if (per_dev[dev] == 0) {
+    int v = 0;
+    per_dev[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return per_dev[dev];
 }
 
 }  // namespace
@@ -80,20 +103,6 @@ int nfst_device_available(void) {
 int64_t nfst_lds_bytes(const nfst_batch *lat) {
   if (!lat) return NFST_ERR_ARG;
   return LdsPlan(lat->max_rows, lat->vocab).fb_bytes(kMinRing, kRawSlotsShared, lat->weighted != 0);
-}
-
-// number of CUs of the current device (cached per process; 256 on MI355X)
-static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-  }
-  return n;
 }
 
 // Ring sizes per sweep from the LDS budget of one workgroup, and which kernel flavour runs.

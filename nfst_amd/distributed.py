@@ -9,7 +9,7 @@ collective to translate.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -28,6 +28,17 @@ def shard_lattices(n_arcs: Sequence[int], world_size: int) -> List[List[int]]:
         shards[r].append(i)
         loads[r] += int(n_arcs[i])
     return [sorted(s) for s in shards]
+
+
+def local_log_z_sum(lat, theta, device=None) -> torch.Tensor:
+    """sum_b log Z[b] of this rank's shard as a float64 scalar tensor.  ``shard_lattices`` hands a
+    rank an empty shard when there are fewer lattices than ranks: such a rank passes ``lat=None``
+    and contributes 0 to the all-reduce instead of launching on an empty batch (which the engine
+    refuses with NFST_ERR_ARG) while its peers wait in the collective."""
+    if lat is None or lat.n_lattices == 0:
+        return torch.zeros((), dtype=torch.float64, device=device if device is not None else "cpu")
+    from . import ops
+    return ops.forward_backward(lat, theta, want_alpha_beta=False, want_posterior=False).logz64.sum()
 
 
 def all_reduce_loss(loss: torch.Tensor, async_op: bool = False, inplace: bool = False):

@@ -63,20 +63,25 @@ class Sampler:
         return s.logq.reshape(-1), samples
 
     def stripping_pad(self, sequences: torch.Tensor) -> torch.Tensor:
-        """samplers.py:162-180: drop marks equal to 0, left-align, cut after the first
-        column that is pad everywhere.  (Vectorised: a stable sort replaces the loop.)"""
+        """samplers.py:162-180: the columns up to the first one that is pad everywhere are walked;
+        marks equal to 0 are dropped, the rest is left-aligned and followed by pad.  Like the
+        reference's loop, a row whose walked part ends in a dropped 0 keeps that 0 right after its
+        last mark (it differs from pad only when pad != 0).  Vectorised: a stable sort replaces the loop."""
         assert len(sequences.shape) == 2
         pad = self.model.__pad__
-        keep = sequences != 0
-        order = torch.sort((~keep).to(torch.int8), dim=1, stable=True).indices
-        packed = torch.gather(sequences, 1, order)
-        n_keep = keep.sum(dim=1, keepdim=True)
-        cols = torch.arange(sequences.shape[1], device=sequences.device)[None, :]
-        packed = torch.where(cols < n_keep, packed, torch.full_like(packed, pad))
         all_pad = (sequences == pad).all(dim=0)
         idx = torch.nonzero(all_pad)
         stop = int(idx[0]) if idx.numel() > 0 else sequences.shape[1] - 1
-        return packed[:, : stop + 1].contiguous()
+        seq = sequences[:, : stop + 1]
+        keep = seq != 0
+        order = torch.sort((~keep).to(torch.int8), dim=1, stable=True).indices
+        packed = torch.gather(seq, 1, order)
+        n_keep = keep.sum(dim=1, keepdim=True)
+        cols = torch.arange(stop + 1, device=sequences.device)[None, :]
+        packed = torch.where(cols < n_keep, packed, torch.full_like(packed, pad))
+        if pad != 0:  # the last write of the reference's loop at position n_keep is that trailing 0
+            packed = torch.where((cols == n_keep) & (seq[:, -1:] == 0), torch.zeros_like(packed), packed)
+        return packed.contiguous()
 
 
 class ProposalSampler(Sampler):

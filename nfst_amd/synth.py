@@ -281,6 +281,18 @@ def batch_arcs(lattices: Sequence[SynthLattice]):
     return n_rows, arc_off, src, label, dst, weight
 
 
+def without_parallel_arcs(l: SynthLattice) -> SynthLattice:
+    """The lattice with one arc kept per (src, dst) pair (the one with the smallest label): the
+    reference's ``compute_beta_parallel`` never releases a state with two arcs to the same
+    destination, so its algorithm can only be timed on such lattices."""
+    nl = l.src != l.dst
+    key = l.src[nl].astype(np.int64) * l.n_rows + l.dst[nl]
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    w = None if l.weight is None else l.weight[nl][first]
+    return _finish(l.n_rows, l.vocab, l.src[nl][first], l.label[nl][first], l.dst[nl][first], w)
+
+
 def bench_batch(
     n_lattices: int, first_seed: int = 1234, n_states: Optional[int] = None, **kw
 ) -> List[SynthLattice]:

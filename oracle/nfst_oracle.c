@@ -392,7 +392,8 @@ int orc_score_paths(int n_rows, int64_t A, const int32_t *src, const int32_t *la
  * beta [S] float32 out.  Returns the number of frontier iterations. */
 int orc_beta_dense_frontier(const int64_t *transition, int S, int V, int H,
                             const float *emb, const float *Wx, const float *Wh,
-                            const float *W, const float *bias, float *beta) {
+                            const float *W, const float *bias, float *beta, int n_threads) {
+  if (n_threads < 1) n_threads = 1;  /* rows of the [S,S] cell table in parallel, like torch's intra-op threads */
   int32_t *edges = (int32_t *)calloc((size_t)S * S, sizeof(int32_t));
   float *parents = (float *)calloc((size_t)S, sizeof(float));
   uint8_t *visited = (uint8_t *)calloc((size_t)S, 1);
@@ -402,7 +403,6 @@ int orc_beta_dense_frontier(const int64_t *transition, int S, int V, int H,
   float *pmsg_emb = (float *)calloc((size_t)S * S * H, sizeof(float));
   float *xw = (float *)malloc(sizeof(float) * (size_t)V * H);             /* Wx e(l) per label */
   float *hw = (float *)malloc(sizeof(float) * (size_t)S * H);             /* Wh bhat(s) */
-  float *msg = (float *)malloc(sizeof(float) * (size_t)H);
   for (int i = 0; i < S; ++i)
     for (int j = 0; j < V; ++j) {
       int64_t to = transition[(size_t)i * V + j];
@@ -426,6 +426,7 @@ int orc_beta_dense_frontier(const int64_t *transition, int S, int V, int H,
       init = 0;
     } else {
       /* beta[cur] = sum over the transposed message row; bhat = sum q * msg_emb */
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 8)
       for (int s = 0; s < S; ++s) {
         if (!cur[s]) continue;
         float b = 0.0f;
@@ -446,7 +447,9 @@ int orc_beta_dense_frontier(const int64_t *transition, int S, int V, int H,
         for (int d = 0; d < H; ++d) acc += bhat[(size_t)s * H + d] * Wh[(size_t)e * H + d];
         hw[(size_t)s * H + e] = acc;
       }
+#pragma omp parallel for num_threads(n_threads) schedule(static)
     for (int s = 0; s < S; ++s) {
+      float msg[512];  /* H <= 512 (checked by the wrapper) */
       /* the reference evaluates all S x S cells each iteration; the cost model
        * is kept (the loop below touches every cell of every row) but only the
        * frontier rows are stored, exactly what scorers.py:828-843 keeps. */
@@ -475,6 +478,6 @@ int orc_beta_dense_frontier(const int64_t *transition, int S, int V, int H,
     }
   }
   free(edges); free(parents); free(visited); free(cur); free(bhat); free(pmsg);
-  free(pmsg_emb); free(xw); free(hw); free(msg);
+  free(pmsg_emb); free(xw); free(hw);
   return iters;
 }

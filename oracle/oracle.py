@@ -189,16 +189,20 @@ def score_paths(n_rows: int, src, label, dst, score, marks: np.ndarray):
     return tot, end
 
 
-def beta_dense_frontier(transition: np.ndarray, emb, Wx, Wh, W, bias) -> Tuple[np.ndarray, int]:
-    """compute_beta_parallel (scorers.py:753-856) restated; float32 probability domain."""
+def beta_dense_frontier(transition: np.ndarray, emb, Wx, Wh, W, bias, n_threads: int = 1) -> Tuple[np.ndarray, int]:
+    """compute_beta_parallel (scorers.py:753-856) restated; float32 probability domain.  ``n_threads``
+    OpenMP threads share the rows of the dense [S, S] cell table (results do not depend on it)."""
     transition = np.ascontiguousarray(transition, np.int64)
     S, V = transition.shape
     emb = np.ascontiguousarray(emb, np.float32); H = emb.shape[1]
     Wx = np.ascontiguousarray(Wx, np.float32); Wh = np.ascontiguousarray(Wh, np.float32)
     W = np.ascontiguousarray(W, np.float32).reshape(-1); bias = np.ascontiguousarray(bias, np.float32)
+    if H > 512:
+        raise ValueError("H <= 512")
     beta = np.empty(S, np.float32)
     it = lib().orc_beta_dense_frontier(_p(transition, C.c_int64), S, V, H, _p(emb, C.c_float), _p(Wx, C.c_float),
-                                       _p(Wh, C.c_float), _p(W, C.c_float), _p(bias, C.c_float), _p(beta, C.c_float))
+                                       _p(Wh, C.c_float), _p(W, C.c_float), _p(bias, C.c_float), _p(beta, C.c_float),
+                                       int(n_threads))
     return beta, int(it)
 
 

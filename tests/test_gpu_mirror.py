@@ -18,12 +18,6 @@ pytestmark = pytest.mark.gpu
 PAD, BOS, EOS = synth.PAD, synth.BOS, synth.EOS
 
 
-@pytest.fixture(scope="module")
-def dev():
-    assert torch.cuda.is_available()
-    return torch.device("cuda:0")
-
-
 def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 

@@ -18,13 +18,6 @@ PAD, BOS, EOS = synth.PAD, synth.BOS, synth.EOS
 TOL = 1e-5
 
 
-@pytest.fixture(scope="module")
-def dev():
-    assert torch.cuda.is_available(), "these tests need the MI355X"
-    assert _lib.lib.nfst_device_available() == 1
-    return torch.device("cuda:0")
-
-
 def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
