@@ -5,27 +5,38 @@
 
 A step is one pass of ``nfst_forward_backward`` (alpha sweep, beta sweep, exact
 log Z, arc posteriors; float32 arithmetic in an extended-exponent probability
-semiring) over one batch of synthetic lattices that is already resident in HBM:
-BASELINE.json configs[1], 256 lattices of ~2k states / ~20k arcs per GPU
-(``nfst_amd.synth.bench_batch``, seeds 1234+i).  With N > 1 every rank owns its
-own 256 lattices (weak scaling, no data-path collective) and the only exchange
-is the RCCL all-reduce of the scalar loss sum(log Z) at the end of each step.
+semiring) over one batch of synthetic lattices that is already resident in HBM
+(``nfst_amd.synth.bench_batch``, lattices of ~2k states / ~20k arcs, seeds 1234+i).
+
+Workload: N = 1 runs BASELINE.json configs[1] (256 lattices on the GPU); N > 1 runs
+configs[3]'s shape, 1024 lattices per GPU (8192 over 8 GPUs).  Every rank owns its own
+lattices (weak scaling, no data-path collective); the only exchange is the RCCL
+all-reduce of the scalar loss sum(log Z) at the end of each step.  The other per-GPU
+batch size is timed as well and reported under ``config.aux`` ("per_gpu_256" /
+"per_gpu_1024") at every N, so that scaling can be read at equal per-GPU work.
+
+``python bench.py --gpus N`` without WORLD_SIZE in the environment starts its own N rank
+processes (fresh children, before this process touches the GPU); under
+``torch.distributed.run`` it is one of the ranks.
 
 Rank 0 prints one JSON line: value = lattice arcs processed by all ranks per
 second; ``roofline`` = algorithmic HBM bytes (32 B/arc +
 24 B/state) per launch / average kernel duration from HIP events, against the
 8 TB/s HBM3E peak; ``cpu_baseline`` = the CPU oracle's float64 forward-backward
 (oracle/nfst_oracle.c, OpenMP over lattices) on the same batch on this box's
-host cores, rank 0 at N=1 only.
+host cores, rank 0 at N=1 only.  ``config.aux`` (N = 1): timed lines for the other
+BASELINE configs -- [2] 64 SNIPS-shaped lattices, [4] sampling K=16 + Viterbi with
+float32 / bfloat16-rounded scores --, for shallower / deeper lattices of the same size,
+and for the step with caller-supplied per-arc scores.
 """
 import argparse
+import collections
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,6 +44,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+# ----------------------------------------------------------------------------- self-launch
+def self_launch(n: int) -> int:
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set),
+    wait for all of them; a failing rank ends the others.  Runs before anything in this process
+    touches the GPU -- a process that has initialised the GPU is never re-executed.  Only the
+    standard library is used here."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:  # the exact children started above, by PID
+                    q.terminate()
+    return rc
+
+
+# ----------------------------------------------------------------------------- helpers
 def pmc_traffic_bytes():
     """HBM bytes per k_forward_backward launch from the committed rocprofv3 PMC passes
     (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in separate runs of this benchmark, KiB per
@@ -53,6 +98,7 @@ def pmc_traffic_bytes():
 def cpu_baseline(lats, theta, budget_s=12.0):
     """The oracle (a port of the reference's path-sum semantics, float64) timed on
     the host cores over the same lattices; repeated until ~budget_s of work."""
+    import numpy as np
     from oracle import oracle as O
     from nfst_amd import synth
 
@@ -70,28 +116,40 @@ def cpu_baseline(lats, theta, budget_s=12.0):
     out = {"value": dp * reps / dt, "unit": "lattice-arcs/s", "cores": cores, "kind": "port",
            "sample": f"{len(lats)} lattices ({dp} arcs) x {reps} passes, float64 log-semiring forward-backward, "
                      f"OpenMP over lattices, {dt:.1f} s"}
-    # the reference's own algorithm (compute_beta_parallel: dense [S,S] frontier loop, H=8) on one
-    # small lattice -- its cost grows ~S^3, a 2k-state lattice takes minutes
+    # cpu_ref_dense: the reference's own algorithm
+    # (compute_beta_parallel: dense [S,S] cell table, frontier loop, H = 8 label-only weights; cost
+    # ~S^3) restated in C, on the first two lattices of the batch at their full size (S ~ 2000) with
+    # parallel arcs removed (the reference's algorithm never finishes a lattice that has them,
+    # SURVEY 8a-3); the rows of the cell table are shared by OpenMP threads like torch's intra-op
+    # threads share the reference's einsums.  The reference's Python takes ~200 s per such lattice
+    # on 8 cores.
     try:
-        small = synth.layered_lattice(1234, n_states=300, avg_degree=8.0, vocab=64, width=8, span=4)
-        _, tr = small.dense()
         rng = np.random.default_rng(0)
         H = 8
-        emb, Wx = rng.normal(size=(64, H)).astype(np.float32), (0.3 * rng.normal(size=(H, H))).astype(np.float32)
-        Wh, W, bias = np.zeros((H, H), np.float32), rng.normal(size=H).astype(np.float32), np.zeros(H, np.float32)
-        t0 = time.perf_counter()
-        O.beta_dense_frontier(tr, emb, Wx, Wh, W, bias)
+        V = lats[0].vocab
+        emb, Wx = rng.normal(size=(V, H)).astype(np.float32), (0.3 * rng.normal(size=(H, H))).astype(np.float32)
+        Wh, W, bias = np.zeros((H, H), np.float32), np.full(H, -2.3 / H, np.float32), np.full(H, 4.0, np.float32)
+        arcs_done, t0 = 0, time.perf_counter()
+        sizes = []
+        for l in lats[:2]:
+            l2 = synth.without_parallel_arcs(l)
+            _, tr = l2.dense()
+            O.beta_dense_frontier(tr, emb, Wx, Wh, W, bias, n_threads=cores)
+            arcs_done += int((l2.src != l2.dst).sum())
+            sizes.append(l2.n_rows - 1)
         dt = time.perf_counter() - t0
-        out["reference_dense_frontier"] = {"value": int((small.src != small.dst).sum()) / dt, "unit": "lattice-arcs/s",
-                                           "cores": 1, "sample": f"one lattice S=300, beta sweep only, {dt:.2f} s"}
+        out["cpu_ref_dense"] = {"value": arcs_done / dt, "unit": "lattice-arcs/s", "cores": cores,
+                                "sample": f"{len(sizes)} lattices, S = {sizes}, beta sweep only, dense-frontier algorithm of "
+                                          f"scorers.py:753-856 restated in C (float32, H = 8), {dt:.2f} s"}
     except Exception as e:  # the extra line is informational
-        out["reference_dense_frontier"] = {"error": str(e)}
+        out["cpu_ref_dense"] = {"error": str(e)}
     return out
 
 
 def measured_copy_gbs(dev, mib: int = 1024, reps: int = 10) -> float:
     """What a plain device-to-device copy of 1 GiB reaches on this card (read + write bytes per
     second), the figure SURVEY.md section 8d wants beside the 8 TB/s nameplate peak."""
+    import torch
     src = torch.empty(mib << 20, dtype=torch.uint8, device=dev)
     dst = torch.empty_like(src)
     dst.copy_(src)
@@ -104,13 +162,214 @@ def measured_copy_gbs(dev, mib: int = 1024, reps: int = 10) -> float:
     return 2.0 * src.numel() * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def time_op(fn, iters: int, warmup: int = 5) -> float:
+    """ms per call of ``fn`` (launches on torch's current stream, which is the stream the ops use)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+class Stepper:
+    """The benchmark step over one resident batch: launch + loss reduction (+ RCCL all-reduce).
+
+    sum_b log Z[b] comes out of the kernel itself (atomic adds into one of three rotating slots):
+    the loss of a step needs no reduction kernel.  TRIPLES slot triples take turns, so a step's
+    slot is cleared only 2 * TRIPLES steps later: its all-reduce over ranks has that long to
+    finish and no launch ever queues behind a collective."""
+    TRIPLES = 4
+
+    def __init__(self, lat, theta, dev, world, mode="fb", fused=True, arc_scores=None):
+        import torch
+        self.torch = torch
+        self.lat, self.theta, self.world, self.mode, self.fused = lat, theta, world, mode, fused
+        self.arc_scores = arc_scores
+        self.total = torch.zeros(3 * self.TRIPLES, dtype=torch.float64, device=dev)
+        self.out, self.i = None, 0
+        self.pending = collections.deque()
+
+    def slot_of(self, i):
+        return i % self.TRIPLES, (i // self.TRIPLES) % 3
+
+    def launch(self):
+        from nfst_amd import ops
+        j, slot = self.slot_of(self.i)
+        self.i += 1
+        kw = dict(total=self.total[3 * j:3 * j + 3], total_slot=slot) if self.fused else {}
+        if self.mode == "fb":  # outputs are allocated by the first call and overwritten afterwards (steady state)
+            self.out = ops.forward_backward(self.lat, self.theta, arc_scores=self.arc_scores, want_alpha_beta=True,
+                                            want_posterior=True, out=self.out, **kw)
+        elif self.mode == "fb_sweeps_only":
+            self.out = ops.forward_backward(self.lat, self.theta, want_alpha_beta=False, want_posterior=False, out=self.out, **kw)
+        else:
+            return ops.backward(self.lat, self.theta, want_logbeta=False)
+        return self.out
+
+    def reduce_loss(self, r):
+        """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously and in place, in
+        the slot the kernel left it in: the collectives of the last steps overlap the sweeps of the
+        next ones; the oldest is waited for (long finished) before its slot comes up for clearing"""
+        from nfst_amd.distributed import all_reduce_loss
+        j, slot = self.slot_of(self.i - 1)
+        loss = self.total[3 * j + slot:3 * j + slot + 1] if self.fused else r.logz64.sum()
+        if self.world > 1:
+            while len(self.pending) >= (2 * self.TRIPLES - 2 if self.fused else 1):
+                self.pending.popleft().wait()
+            loss, work = all_reduce_loss(loss, async_op=True, inplace=self.fused)
+            self.pending.append(work)
+        return loss
+
+    def drain(self):
+        while self.pending:
+            self.pending.popleft().wait()
+
+
+def timed_region(stepper, steps, warmup, world, dev, event_every=8, launch=None):
+    """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize on
+    both sides.  Returns (wall seconds -- max over ranks --, list of per-launch kernel ms, one per
+    event window, last loss).  Kernel duration: HIP events on the launch stream around every run of
+    `span` back-to-back launches, divided by span (nothing else runs on that stream, so this is an
+    upper bound of the average kernel duration; an event pair around every single launch adds
+    ~2.5 us of command gaps to each and reads 5 % high against rocprofv3's kernel trace)."""
+    import torch
+    import torch.distributed as dist
+    launch = launch or stepper.launch
+    loss = None
+    for _ in range(warmup):
+        loss = stepper.reduce_loss(launch())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    span = max(1, min(event_every, steps))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps // span)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        g, k = divmod(i, span)
+        if k == 0 and g < len(ev):
+            ev[g][0].record()
+        r = launch()
+        if k == span - 1 and g < len(ev):
+            ev[g][1].record()
+        loss = stepper.reduce_loss(r)
+    stepper.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    windows = [a.elapsed_time(b) / span for a, b in ev]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, windows, loss
+
+
+def sum_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch
+    import torch.distributed as dist
+    a = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    return int(a.item())
+
+
+def window_stats(windows):
+    import numpy as np
+    w = np.asarray(windows, dtype=np.float64)
+    return {"n_windows": int(w.size), "min_ms": float(w.min()), "median_ms": float(np.median(w)), "max_ms": float(w.max())}
+
+
+def build_batch(B, rank, width, dev, **pack):
+    from nfst_amd import synth
+    from nfst_amd.lattice import LatticeBatch
+    lats = synth.bench_batch(B, first_seed=1234 + rank * B, width=width)
+    t0 = time.perf_counter()
+    lat = LatticeBatch.from_synth(lats, **pack)
+    pack_s = time.perf_counter() - t0
+    return lats, lat.to(dev), pack_s
+
+
+def aux_single_gpu(dev, theta256, steps):
+    """Timed lines for what the headline does not cover (N = 1): the other BASELINE configs and
+    the shape / score variants of configs[1].  Not the metric; reported under config.aux."""
+    import numpy as np
+    import torch
+    from nfst_amd import ops, synth
+    from nfst_amd.lattice import LatticeBatch
+
+    aux = {}
+    iters = max(10, min(steps, 100))
+
+    def fb_line(lat, theta, arc_scores=None):
+        out = {"o": None}
+
+        def f():
+            out["o"] = ops.forward_backward(lat, theta, arc_scores=arc_scores, out=out["o"])
+        ms = time_op(f, iters)
+        arcs = int(lat.n_dp_arcs.sum())
+        return {"lattices": lat.n_lattices, "arcs": arcs, "max_depth": int(lat.depth.max()), "ms_per_step": ms,
+                "arcs_per_s": arcs / (ms * 1e-3), "roofline_frac": lat.algorithmic_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    # configs[1] variants: shallow / deep lattices of the same size; caller-supplied per-arc scores
+    for width in (64, 4):
+        _, lat, _ = build_batch(256, 0, width, dev)
+        aux[f"configs1_width{width}"] = fb_line(lat, theta256)
+    _, lat, _ = build_batch(256, 0, 16, dev)
+    asc = torch.randn(lat.total_arcs, device=dev) * 0.1
+    aux["configs1_with_arc_scores"] = fb_line(lat, theta256, arc_scores=asc)
+    aux["configs1_beta_only"] = {"ms_per_step": time_op(lambda: ops.backward(lat, theta256, want_logbeta=False), iters)}
+    del lat, asc
+    # configs[2]: 64 SNIPS-shaped lattices (long and narrow: up to ~750 token positions)
+    lats = synth.snips_shaped_batch(64)
+    th = torch.from_numpy(synth.label_scores(64, lats[0].vocab, mean=-1.5, std=0.8)).to(dev)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    aux["configs2_snips_shaped_b64"] = fb_line(lat, th)
+    aux["configs2_snips_shaped_b64"]["viterbi_ms"] = time_op(lambda: ops.viterbi(lat, th), iters)
+    # configs[4]: posterior sampling K = 16 + Viterbi on transliteration-shaped (edit) lattices,
+    # float32 scores vs the same scores rounded to bfloat16 (float32 accumulation either way)
+    rng = np.random.default_rng(4)
+    V = 64
+    lats = []
+    for i in range(256):
+        x = rng.integers(3, V, size=int(rng.integers(6, 15))).tolist()
+        y = rng.integers(3, V, size=int(rng.integers(6, 15))).tolist()
+        lats.append(synth.edit_lattice(x, y, vocab=V, seed=100 + i))
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    th32 = torch.from_numpy(synth.label_scores(12, V, mean=-1.0, std=0.7)).to(dev)
+    thbf = th32.to(torch.bfloat16).to(torch.float32)
+    T = int(lat.depth.max()) + 1
+    line = {"lattices": 256, "K": 16, "arcs": int(lat.n_dp_arcs.sum()), "max_len": T}
+    for tag, th in (("f32", th32), ("bf16_scores", thbf)):
+        line[f"sample_k16_ms_{tag}"] = time_op(lambda: ops.sample_paths(lat, th, 16, max_len=T, seed=1), iters)
+        line[f"viterbi_ms_{tag}"] = time_op(lambda: ops.viterbi(lat, th), iters)
+    z32 = ops.backward(lat, th32, want_logbeta=False).logz64
+    zbf = ops.backward(lat, thbf, want_logbeta=False).logz64
+    line["max_abs_logz_diff_bf16_scores"] = float((z32 - zbf).abs().max())
+    line["walks_per_s_f32"] = 256 * 16 / (line["sample_k16_ms_f32"] * 1e-3)
+    aux["configs4_sampling_viterbi"] = line
+    return aux
+
+
+# ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--lattices-per-gpu", type=int, default=256)
+    ap.add_argument("--lattices-per-gpu", type=int, default=0,
+                    help="0 = BASELINE: 256 at N = 1 (configs[1]), 1024 at N > 1 (configs[3]: 8192 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="only the headline line (no config.aux measurements)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--slots", type=int, default=0, help="arc slots per lane of a tile (0 = packer's choice)")
     ap.add_argument("--no-compact", action="store_true", help="32-bit arc records instead of the compact tile format")
@@ -122,16 +381,26 @@ def main():
     ap.add_argument("--torch-sum", action="store_true", help="reduce the loss with torch.sum instead of the kernel's fused total")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU, no kernel, no number: ranks rendezvous over gloo, pack a few lattices, all-reduce a "
+                         "scalar and rank 0 prints a line with value null (tests of the launcher on a CPU box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # before anything touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, rank, world)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -152,133 +421,74 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from nfst_amd import ops, synth
-    from nfst_amd.lattice import LatticeBatch
-    from nfst_amd.distributed import all_reduce_loss
+    from nfst_amd import synth
 
-    B = args.lattices_per_gpu
-    lats = synth.bench_batch(B, first_seed=1234 + rank * B, width=args.width)
+    B = args.lattices_per_gpu or (256 if world == 1 else 1024)
+    pack = dict(slots_per_lane=args.slots, group_mode=args.group_mode, no_compact=args.no_compact)
+    lats, lat, pack_s = build_batch(B, rank, args.width, dev, **pack)
     theta_np = synth.label_scores(1, 256)
-    t0 = time.perf_counter()
-    lat = LatticeBatch.from_synth(lats, slots_per_lane=args.slots, group_mode=args.group_mode, no_compact=args.no_compact)
-    pack_s = time.perf_counter() - t0
-    lat = lat.to(dev)
     theta = torch.from_numpy(theta_np).to(dev)
     arcs = int(lat.n_dp_arcs.sum())
     alg_bytes = lat.algorithmic_bytes("forward_backward")
 
-    state = {"out": None, "i": 0}
-    # sum_b log Z[b] comes out of the kernel itself (atomic adds into one of three rotating slots):
-    # the loss of a step needs no reduction kernel.  TRIPLES slot triples take turns, so a step's
-    # slot is cleared only 2 * TRIPLES steps later: its all-reduce over ranks has that long to
-    # finish and no launch ever queues behind a collective.
-    TRIPLES = 4
-    total = torch.zeros(3 * TRIPLES, dtype=torch.float64, device=dev)
     fused = args.mode != "bwd" and not args.torch_sum and not args.graph  # a captured launch has one fixed slot
-
-    def slot_of(i):
-        return i % TRIPLES, (i // TRIPLES) % 3
-
-    def run():
-        # outputs are allocated by the first call and overwritten afterwards (steady state)
-        j, slot = slot_of(state["i"])
-        state["i"] += 1
-        kw = dict(total=total[3 * j:3 * j + 3], total_slot=slot) if fused else {}
-        if args.mode == "fb":
-            state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=True, want_posterior=True, out=state["out"], **kw)
-        elif args.mode == "fb_sweeps_only":
-            state["out"] = ops.forward_backward(lat, theta, want_alpha_beta=False, want_posterior=False, out=state["out"], **kw)
-        else:
-            return ops.backward(lat, theta, want_logbeta=False)
-        return state["out"]
-
-    import collections
-    pending = collections.deque()
-
-    def reduce_loss(r):
-        """sum of log Z of this rank, all-reduced over ranks (RCCL) asynchronously and in place, in
-        the slot the kernel left it in: the collectives of the last steps overlap the sweeps of the
-        next ones; the oldest is waited for (long finished) before its slot comes up for clearing"""
-        j, slot = slot_of(state["i"] - 1)
-        loss = total[3 * j + slot:3 * j + slot + 1] if fused else r.logz64.sum()
-        if world > 1:
-            while len(pending) >= (2 * TRIPLES - 2 if fused else 1):
-                pending.popleft().wait()
-            loss, work = all_reduce_loss(loss, async_op=True, inplace=fused)
-            pending.append(work)
-        return loss
+    st = Stepper(lat, theta, dev, world, mode=args.mode, fused=fused)
 
     # --graph: a step is launched by replaying a HIP graph of the forward-backward kernel (the
-    # engine allocates nothing and keeps no state, so one warm-up call makes it capturable); the
-    # reduction of the loss and its all-reduce follow on the same stream.  Default: the kernel is
-    # launched from Python every step (faster here).
-    use_graph = args.graph
-    graph = None
-    if use_graph:
-        run()
+    # engine allocates nothing, so one warm-up call makes it capturable); the reduction of the loss
+    # and its all-reduce follow on the same stream.  Default: the kernel is launched from Python
+    # every step (faster here).
+    launch = None
+    if args.graph:
+        if args.mode == "bwd":
+            raise SystemExit("--mode bwd is a diagnostic: not with --graph")
+        st.launch()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
-                run()
+                st.launch()
         torch.cuda.current_stream().wait_stream(side)
 
-    def launch():
-        if graph is not None:
+        def launch():
             graph.replay()
-            return state["out"] if args.mode != "bwd" else bwd_out["r"]
-        return run()
+            return st.out
 
-    bwd_out = {"r": None}
-    if args.mode == "bwd" and use_graph:
-        raise SystemExit("--mode bwd is a diagnostic: not with --graph")
+    dt, windows, loss = timed_region(st, args.steps, args.warmup, world, dev, args.event_every, launch)
+    total_arcs = sum_over_ranks(arcs, world, dev)
+    kern_ms = float(np.mean(windows))
 
-    def step():
-        r = launch()
-        return r, reduce_loss(r)
+    # the other per-GPU batch size of the BASELINE configs, every rank, same protocol, fewer steps
+    aux = {}
+    default_shape = args.lattices_per_gpu == 0 and args.mode == "fb" and args.width == 16 and not args.graph
+    if default_shape and not args.no_aux:
+        B2 = 1024 if B == 256 else 256
+        key = {256: "per_gpu_256", 1024: "per_gpu_1024"}
+        del st
+        lats2, lat2, _ = build_batch(B2, rank, args.width, dev, **pack)
+        st2 = Stepper(lat2, theta, dev, world, fused=True)
+        steps2 = max(8, min(args.steps, 100))
+        dt2, win2, _ = timed_region(st2, steps2, min(args.warmup, 10), world, dev, args.event_every)
+        arcs2 = sum_over_ranks(int(lat2.n_dp_arcs.sum()), world, dev)
+        k2 = float(np.mean(win2))
+        aux[key[B2]] = {"workload": f"{B2} lattices per GPU ({'configs[3]: 8192 over 8 GPUs' if B2 == 1024 else 'configs[1]'})",
+                        "value": arcs2 * steps2 / dt2, "unit": "lattice-arcs/s", "n_gpus": world, "steps": steps2,
+                        "ms_per_step": dt2 / steps2 * 1e3, "kernel_ms": k2,
+                        "roofline_frac": lat2.algorithmic_bytes() / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        aux[key[B]] = "the headline line"
+        del st2, lat2, lats2
+        if world == 1:
+            try:
+                aux.update(aux_single_gpu(dev, theta, args.steps))
+            except Exception as e:  # informational lines must not cost the headline
+                aux["error"] = f"{type(e).__name__}: {e}"
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    # kernel duration: HIP events on the launch stream around every run of `span` back-to-back
-    # launches of the timed region, divided by span (nothing else runs on that stream, so this is
-    # an upper bound of the average kernel duration; an event pair around every single launch adds
-    # ~2.5 us of command gaps to each and reads 5 % high against rocprofv3's kernel trace)
-    span = max(1, min(args.event_every, args.steps))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps // span)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        g, k = divmod(i, span)
-        if k == 0 and g < len(ev):
-            ev[g][0].record()
-        r = launch()
-        if k == span - 1 and g < len(ev):
-            ev[g][1].record()
-        loss = reduce_loss(r)
-    while pending:
-        pending.popleft().wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / span
-    total_arcs = arcs
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        a = torch.tensor([arcs], dtype=torch.float64, device=dev)
-        dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        total_arcs = int(a.item())
     if rank == 0:
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         tbytes, tsrc = pmc_traffic_bytes() if (args.mode == "fb" and B == 256 and args.width == 16) else (None, None)
+        shape = "BASELINE configs[1]" if B == 256 else ("BASELINE configs[3] (8192 lattices over 8 GPUs)" if B == 1024 else "custom")
         out = {
             "metric": "lattice-arcs/sec forward-backward (log-Z)",
             "value": total_arcs * args.steps / dt,
@@ -292,23 +502,54 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {B} synthetic lattices per GPU, ~2k states / ~20k arcs "
+            "config": {"workload": f"{shape}: {B} synthetic lattices per GPU, ~2k states / ~20k arcs "
                                    f"(layer width {args.width}), alpha+beta+logZ+arc posteriors",
-                       "lattices_per_gpu": B, "arcs_per_gpu": arcs, "vocab": 256,
-                       "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()), "host_pack_s": pack_s,
-                       "launch": "hip_graph_replay" if use_graph else "python",
+                       "lattices_per_gpu": B, "lattices_total": B * world, "arcs_per_gpu": arcs, "vocab": 256,
+                       "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()),
+                       "host_pack_s": pack_s,
+                       "launch": "hip_graph_replay" if args.graph else "python",
                        "loss_reduction": "fused in the kernel (atomic adds)" if fused else "torch.sum",
-                       "lds_reserve_kb": int(os.environ.get("NFST_LDS_RESERVE_KB", "0") or 0)},
+                       "lds_reserve_kb": int(os.environ.get("NFST_LDS_RESERVE_KB", "0") or 0),
+                       "aux": aux},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,
                          "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
-                         "kernel": "k_forward_backward", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+                         "hw_utilisation_from_traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel": "k_forward_backward", "kernel_ms": kern_ms, "kernel_ms_windows": window_stats(windows),
+                         "algorithmic_bytes": alg_bytes},
         }
         out["roofline"]["hbm_copy_measured"] = measured_copy_gbs(dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lats, theta_np, args.cpu_budget)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(lats[:256], theta_np, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def rehearse_cpu(args, rank, world):
+    """The launcher and the rank plumbing on a box without a GPU: gloo rendezvous, the host packer on a
+    few small lattices, one all-reduce.  Measures nothing and says so."""
+    import torch
+    import torch.distributed as dist
+    from nfst_amd import synth
+    from nfst_amd.distributed import all_reduce_loss
+    from nfst_amd.lattice import LatticeBatch
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    lats = [synth.layered_lattice(1234 + rank * 4 + i, n_states=60, avg_degree=4.0, vocab=32, width=4, span=2) for i in range(4)]
+    lat = LatticeBatch.from_synth(lats)
+    arcs = torch.tensor([float(lat.n_dp_arcs.sum())], dtype=torch.float64)
+    total = all_reduce_loss(arcs)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "lattice-arcs/sec forward-backward (log-Z)", "value": None, "unit": "lattice-arcs/s",
+                          "n_gpus": world, "rehearsal": "cpu: no kernel was run, nothing was measured",
+                          "arcs_packed_all_ranks": int(total.item())}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -28,8 +28,9 @@
  *                                      (scorers.py:1037-1054)
  *   nfst_beta_logits                   beta-logit gather (scorers.py:581-593)
  *   nfst_gather_label_scores           WFSTScorer (scorers.py:1671-1687)
- *   nfst_path_logprob                  StaticRNNScorer.evaluate_seq_with_temp
- *                                      gather (scorers.py:1564-1611),
+ *   nfst_path_logprob (+ _backward)    StaticRNNScorer.evaluate_seq_with_temp
+ *                                      gather (scorers.py:1564-1611) and its gradient
+ *                                      (lightning.py:511-516 trains through it),
  *                                      GPT2Wrapper.forward (transformer.py:45-52)
  *   nfst_iwae                          Estimators.iwae (estimatros.py:11-44)
  *
@@ -57,7 +58,7 @@
 extern "C" {
 #endif
 
-#define NFST_ABI_VERSION 3
+#define NFST_ABI_VERSION 4
 
 /* error codes */
 #define NFST_OK 0
@@ -324,8 +325,9 @@ int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, f
 
 /*
  * Fused log_softmax + gather + mask-sum over sequences: scores [N, T, V] float32,
- * marks [N, T] int64, out [N] float32.  Masks are the reference's
- * (scorers.py:89-134): bos/pad illegal, after eos/pad only pad, beyond
+ * marks [N, T] int64, out [N] float32.
+ * mask_mode NFST_MASK_STATICRNN -- StaticRNNScorer.evaluate_seq_with_temp (scorers.py:1564-1611):
+ * masks as in scorers.py:89-134: bos/pad illegal, after eos/pad only pad, beyond
  * max_length only eos (max_length < 0 disables); the pad column of scores is
  * zeroed (pad_masking_3d, scorers.py:189-192); positions holding pad contribute
  * 0.  normalize = 0 skips the log_softmax (self_normalized = False).
@@ -333,10 +335,30 @@ int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, f
  * training branch (scorers.py:1502-1528, 1584-1592): weight 1 - smoothing on the
  * realised mark, smoothing / (legal marks - 1) on the other legal marks, values
  * clamped to +-1e9.
+ * mask_mode NFST_MASK_GPT2 -- GPT2Wrapper.forward (modules/transformer.py:45-52): scores are
+ * the language model's logits for the bos-shifted input, marks is gold_x (the sequence with one
+ * trailing pad); the pad logit is replaced by -1e8, there are no legality masks, positions
+ * holding pad contribute 0 (bos, eos, max_length are ignored; temp = 1, normalize = 1 there).
  */
+#define NFST_MASK_STATICRNN 0
+#define NFST_MASK_GPT2 1
 int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int32_t t,
                       int32_t vocab, int32_t pad, int32_t bos, int32_t eos, int32_t max_length,
-                      float temp, int32_t normalize, float smoothing, float *out, void *stream);
+                      float temp, int32_t normalize, float smoothing, int32_t mask_mode, float *out,
+                      void *stream);
+
+/*
+ * Backward of nfst_path_logprob: grad_scores [N, T, V] = grad_out[n] * d out[n] / d scores[n, t, v]
+ * (every element is written).  The reference trains p~ straight through this op:
+ * p_loss = -(num_prob - denom_prob).mean() (modules/lightning.py:511-516) back-propagates through
+ * evaluate_seq_with_temp.  Per row: (target - softmax * sum(target)) / temp with the one-hot or
+ * label-smoothed target; the pad column and rows whose mark is pad get 0.  The row is recomputed
+ * from scores (nothing is saved by the forward pass): N T V 4 bytes read, as many written.
+ */
+int nfst_path_logprob_backward(const float *scores, const int64_t *marks, const float *grad_out, int64_t n,
+                               int32_t t, int32_t vocab, int32_t pad, int32_t bos, int32_t eos,
+                               int32_t max_length, float temp, int32_t normalize, float smoothing,
+                               int32_t mask_mode, float *grad_scores, void *stream);
 
 /* log_w [B,K] = log_p - log_q ; log_marginal [B] = logsumexp_k(log_w) - log K */
 int nfst_iwae(const float *log_p, const float *log_q, int32_t b, int32_t k, float *log_w,

@@ -347,40 +347,74 @@ int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, f
   return hip_status(hipGetLastError());
 }
 
+// shared argument checks and the variant table of the 16-byte streaming kernels: a row lies on a
+// quarter wave (up to 128 slots of 16 bytes, 8 per lane) or a half wave, four or two rows side by
+// side: the per-row instructions (two reductions, masks) are shared by the rows of a wave, and the
+// slots a row wastes are at most 15 / 31.
+static int plp_check(const void *scores, const void *marks, int64_t n, int32_t t, int32_t vocab, float temp,
+                     float smoothing, int32_t mask_mode) {
+  if (!scores || !marks || n <= 0 || t <= 0 || vocab <= 0 || !(temp > 0.0f)) return NFST_ERR_ARG;
+  if (!(smoothing >= 0.0f && smoothing < 1.0f)) return NFST_ERR_ARG;  // scorers.py:1514
+  if (mask_mode != NFST_MASK_STATICRNN && mask_mode != NFST_MASK_GPT2) return NFST_ERR_ARG;
+  if (n > 0x7fffffffll) return NFST_ERR_LIMIT;
+  return NFST_OK;
+}
+static int plp_variant(const void *p0, const void *p1, int32_t vocab) {
+  const bool v4 = vocab % 4 == 0 && (((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0 && vocab <= 1024;
+  if (!v4) return 0;
+  const int f4 = vocab / 4;
+  return f4 <= 128 ? (f4 + 15) / 16 : 8 + (f4 + 31) / 32;
+}
+#define NFST_PLP_SWITCH(u, LAUNCH, FALLBACK) \
+  switch (u) {                               \
+    case 0: FALLBACK; break;                 \
+    case 1: LAUNCH(1, 8, 16); break;         \
+    case 2: LAUNCH(2, 4, 16); break;         \
+    case 3: LAUNCH(3, 4, 16); break;         \
+    case 4: LAUNCH(4, 2, 16); break;         \
+    case 5: LAUNCH(5, 2, 16); break;         \
+    case 6: LAUNCH(6, 2, 16); break;         \
+    case 7: LAUNCH(7, 1, 16); break;         \
+    case 8: LAUNCH(8, 1, 16); break;         \
+    case 13: LAUNCH(5, 2, 32); break; /* 129 .. 160 slots */ \
+    case 14: LAUNCH(6, 2, 32); break;        \
+    case 15: LAUNCH(7, 1, 32); break;        \
+    default: LAUNCH(8, 1, 32); break; /* 16: up to 256 slots */ \
+  }
+
 int nfst_path_logprob(const float *scores, const int64_t *marks, int64_t n, int32_t t, int32_t vocab,
                       int32_t pad, int32_t bos, int32_t eos, int32_t max_length, float temp,
-                      int32_t normalize, float smoothing, float *out, void *stream) {
-  if (!scores || !marks || !out || n <= 0 || t <= 0 || vocab <= 0 || !(temp > 0.0f)) return NFST_ERR_ARG;
-  if (!(smoothing >= 0.0f && smoothing < 1.0f)) return NFST_ERR_ARG;  // scorers.py:1514
-  if (n > 0x7fffffffll) return NFST_ERR_LIMIT;
+                      int32_t normalize, float smoothing, int32_t mask_mode, float *out, void *stream) {
+  int rc = plp_check(scores, marks, n, t, vocab, temp, smoothing, mask_mode);
+  if (rc) return rc;
+  if (!out) return NFST_ERR_ARG;
 #define NFST_LAUNCH_PLP(NV, RB, L)                                                                         \
   hipLaunchKernelGGL((k_path_logprob_v4<NV, RB, L>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
                      scores, marks, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length,      \
-                     temp, (int)normalize, smoothing, out)
-  // A row lies on a quarter wave (up to 128 slots of 16 bytes, 8 per lane) or a half wave, four or
-  // two rows side by side: the per-row instructions (two reductions, masks) are shared by the rows
-  // of a wave, and the slots a row wastes are at most 15 / 31.
-  const bool v4 = vocab % 4 == 0 && ((uintptr_t)scores & 15) == 0 && vocab <= 1024;
-  const int f4 = vocab / 4, u = f4 <= 128 ? (f4 + 15) / 16 : 8 + (f4 + 31) / 32;
-  if (v4) switch (u) {
-    case 1: NFST_LAUNCH_PLP(1, 8, 16); break;
-    case 2: NFST_LAUNCH_PLP(2, 4, 16); break;
-    case 3: NFST_LAUNCH_PLP(3, 4, 16); break;
-    case 4: NFST_LAUNCH_PLP(4, 2, 16); break;
-    case 5: NFST_LAUNCH_PLP(5, 2, 16); break;
-    case 6: NFST_LAUNCH_PLP(6, 2, 16); break;
-    case 7: NFST_LAUNCH_PLP(7, 1, 16); break;
-    case 8: NFST_LAUNCH_PLP(8, 1, 16); break;
-    case 13: NFST_LAUNCH_PLP(5, 2, 32); break;  // 129 .. 160 slots
-    case 14: NFST_LAUNCH_PLP(6, 2, 32); break;
-    case 15: NFST_LAUNCH_PLP(7, 1, 32); break;
-    default: NFST_LAUNCH_PLP(8, 1, 32); break;  // 16: up to 256 slots
-  }
-  else
-    hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
-                       (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
-                       (int)normalize, smoothing, out);
+                     temp, (int)normalize, smoothing, (int)mask_mode, out)
+  NFST_PLP_SWITCH(plp_variant(scores, nullptr, vocab), NFST_LAUNCH_PLP,
+                  hipLaunchKernelGGL(k_path_logprob, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
+                                     (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
+                                     (int)normalize, smoothing, (int)mask_mode, out))
 #undef NFST_LAUNCH_PLP
+  return hip_status(hipGetLastError());
+}
+
+int nfst_path_logprob_backward(const float *scores, const int64_t *marks, const float *grad_out, int64_t n, int32_t t,
+                               int32_t vocab, int32_t pad, int32_t bos, int32_t eos, int32_t max_length, float temp,
+                               int32_t normalize, float smoothing, int32_t mask_mode, float *grad_scores, void *stream) {
+  int rc = plp_check(scores, marks, n, t, vocab, temp, smoothing, mask_mode);
+  if (rc) return rc;
+  if (!grad_out || !grad_scores) return NFST_ERR_ARG;
+#define NFST_LAUNCH_PLPB(NV, RB, L)                                                                            \
+  hipLaunchKernelGGL((k_path_logprob_bwd_v4<NV, RB, L>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,  \
+                     scores, marks, grad_out, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, \
+                     temp, (int)normalize, smoothing, (int)mask_mode, grad_scores)
+  NFST_PLP_SWITCH(plp_variant(scores, grad_scores, vocab), NFST_LAUNCH_PLPB,
+                  hipLaunchKernelGGL(k_path_logprob_bwd, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scores, marks,
+                                     grad_out, (int)t, (int)vocab, (int)pad, (int)bos, (int)eos, (int)max_length, temp,
+                                     (int)normalize, smoothing, (int)mask_mode, grad_scores))
+#undef NFST_LAUNCH_PLPB
   return hip_status(hipGetLastError());
 }
 

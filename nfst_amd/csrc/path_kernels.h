@@ -530,23 +530,14 @@ __device__ __forceinline__ float row_sum(float v) {
   return (threadIdx.x & 32) ? (c + d) : (a + b);
 }
 
-template <int NV, int RB, int L>
-__global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
-                                                         const int64_t *__restrict__ marks, int T, int V,
-                                                         int pad, int bos, int eos, int max_length,
-                                                         float temp, int normalize, float smoothing,
-                                                         float *out) {
-  __shared__ float part[4];
-  constexpr int HR = 64 / L;  // rows side by side in a wave
-  const int64_t n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ll = lane & (L - 1), hsel = lane / L;
-  const int64_t *mk = marks + n * T;
-  const float rtemp = 1.0f / temp;
-  // Row-level legality (scorers.py:59-83) only depends on three row flags; which of this lane's
-  // 4 NV columns are illegal under each is a lane constant, one bit per column:
-  //   normal / first row: bos, pad;  after eos or pad: everything but pad;  forced end: everything but eos
-  uint32_t m_norm = 0, m_end = 0, m_force = 0;
+// Row-level legality (scorers.py:59-83) only depends on three row flags; which of a lane's 4 NV
+// columns are illegal under each is a lane constant, one bit per column:
+//   normal / first row: bos, pad;  after eos or pad: everything but pad;  forced end: everything but eos.
+// GPT2Wrapper mode has no legality masks (only the columns beyond V are "illegal"); m_pad marks the
+// pad column, whose logit it replaces by -1e8.
+template <int NV, int L>
+__device__ __forceinline__ void lane_masks(int ll, int V, int pad, int bos, int eos, bool gpt2, uint32_t &m_norm,
+                                           uint32_t &m_end, uint32_t &m_force, uint32_t &m_pad) {
 #pragma unroll
   for (int c = 0; c < NV; ++c)
 #pragma unroll
@@ -554,10 +545,33 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
       const int col = (c * L + ll) * 4 + k;
       const uint32_t bit = 1u << (c * 4 + k);
       const bool oob = col >= V;
+      if (gpt2) {
+        if (oob) { m_norm |= bit; m_end |= bit; m_force |= bit; }
+        if (col == pad) m_pad |= bit;
+        continue;
+      }
       if (oob || col == bos || col == pad) m_norm |= bit;
       if (oob || col == bos || col != pad) m_end |= bit;
       if (oob || col == bos || col == pad || col != eos) m_force |= bit;
     }
+}
+
+template <int NV, int RB, int L>
+__global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict__ scores,
+                                                         const int64_t *__restrict__ marks, int T, int V,
+                                                         int pad, int bos, int eos, int max_length,
+                                                         float temp, int normalize, float smoothing, int mode,
+                                                         float *out) {
+  __shared__ float part[4];
+  constexpr int HR = 64 / L;  // rows side by side in a wave
+  const bool gpt2 = mode == 1;  // GPT2Wrapper.forward (transformer.py:45-52): pad logit = -1e8, no legality masks
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ll = lane & (L - 1), hsel = lane / L;
+  const int64_t *mk = marks + n * T;
+  const float rtemp = 1.0f / temp;
+  uint32_t m_norm = 0, m_end = 0, m_force = 0, m_pad = 0;
+  lane_masks<NV, L>(ll, V, pad, bos, eos, gpt2, m_norm, m_end, m_force, m_pad);
   float acc = 0.0f;
   for (int t0 = wave * RB * HR; t0 < T; t0 += 4 * RB * HR) {
     float4 v[RB][NV];
@@ -584,13 +598,13 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
       const int t = min(t0 + r * HR + hsel, T - 1);
       const bool valid = t0 + r * HR + hsel < T;  // the second half's row may be past the end
       float sel;
-      const float lmsk = seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
-      const float lx = ((lab[r] == pad ? 0.0f : lraw[r]) + lmsk) / temp + lmsk;
+      const float lmsk = gpt2 ? 0.0f : seq_mask(lab[r], t, prev[r], pad, bos, eos, max_length);
+      const float lx = ((lab[r] == pad ? (gpt2 ? -1.0e8f : 0.0f) : lraw[r]) + lmsk) / temp + lmsk;
       sel = lx;
       if (normalize || smoothing > 0.0f) {
         const bool first = t == 0;
-        const bool ended = !first && (prev[r] == eos || prev[r] == pad);
-        const bool force = !first && max_length >= 0 && t > max_length && !ended;
+        const bool ended = !gpt2 && !first && (prev[r] == eos || prev[r] == pad);
+        const bool force = !gpt2 && !first && max_length >= 0 && t > max_length && !ended;
         const uint32_t bad = ended ? m_end : (force ? m_force : m_norm);
         float mx = kNegInf;
 #pragma unroll
@@ -599,7 +613,8 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             // the pad column counts as score 0 (scorers.py:1679-1683); it is only legal in `ended` rows
-            const float x = ended ? 0.0f : e[k] * rtemp;
+            // (GPT2Wrapper: the pad logit is -1e8 in every row)
+            const float x = ended ? 0.0f : ((m_pad & (1u << (c * 4 + k))) ? -1.0e8f * rtemp : e[k] * rtemp);
             e[k] = (bad & (1u << (c * 4 + k))) ? kNegInf : x;
             mx = fmaxf(mx, e[k]);
           }
@@ -649,14 +664,24 @@ __global__ __launch_bounds__(256) void k_path_logprob_v4(const float *__restrict
   if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];
 }
 
+// value of column v of a row before the log_softmax: masks + pad handling + temperature
+// (scorers.py:1564-1580; GPT2Wrapper, transformer.py:45-52: pad logit -1e8, no legality masks)
+__device__ __forceinline__ float seq_value(const float *row, int v, int t, int prev, int pad, int bos, int eos,
+                                           int max_length, float temp, bool gpt2) {
+  if (gpt2) return (v == pad ? -1.0e8f : row[v]) / temp;
+  const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
+  return ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+}
+
 __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const int64_t *marks,
                                                       int T, int V, int pad, int bos, int eos,
                                                       int max_length, float temp, int normalize,
-                                                      float smoothing, float *out) {
+                                                      float smoothing, int mode, float *out) {
   __shared__ float part[4];
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t *mk = marks + n * T;
+  const bool gpt2 = mode == 1;
   float acc = 0.0f;
   for (int t = wave; t < T; t += 4) {
     const float *row = scores + ((size_t)n * T + t) * V;
@@ -667,8 +692,7 @@ __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const
       // online max / sum over the lane's slice, then a wave reduction
       float mx = kNegInf, sm = 0.0f;
       for (int v = lane; v < V; v += 64) {
-        const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
-        const float x = ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+        const float x = seq_value(row, v, t, prev, pad, bos, eos, max_length, temp, gpt2);
         if (x > mx) { sm = sm * expf(mx - x) + 1.0f; mx = x; }
         else if (x > kNegInf) sm += expf(x - mx);
       }
@@ -680,23 +704,19 @@ __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const
         sm = a + c;
         mx = nm;
       }
-      const float msk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
-      const float x = ((lab == pad ? 0.0f : row[lab]) + msk) / temp + msk;
+      const float x = seq_value(row, lab, t, prev, pad, bos, eos, max_length, temp, gpt2);
       sel = x - (mx + logf(sm));  // all -inf row: -inf - (-inf + log 0) = NaN, like the reference
     } else {
-      const float msk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
-      sel = ((lab == pad ? 0.0f : row[lab]) + msk) / temp + msk;
+      sel = seq_value(row, lab, t, prev, pad, bos, eos, max_length, temp, gpt2);
     }
     if (smoothing > 0.0f) {
       // label-smoothed target (scorers.py:1502-1528, 1584-1592)
       float lse = 0.0f;
-      const float lmsk = seq_mask(lab, t, prev, pad, bos, eos, max_length);
-      const float lx = ((lab == pad ? 0.0f : row[lab]) + lmsk) / temp + lmsk;
+      const float lx = seq_value(row, lab, t, prev, pad, bos, eos, max_length, temp, gpt2);
       if (normalize) lse = lx - sel;
       float sx = 0.0f, cnt = 0.0f;
       for (int v = lane; v < V; v += 64) {
-        const float msk = seq_mask(v, t, prev, pad, bos, eos, max_length);
-        const float x = ((v == pad ? 0.0f : row[v]) + msk) / temp + msk;
+        const float x = seq_value(row, v, t, prev, pad, bos, eos, max_length, temp, gpt2);
         if (x > kNegInf) { sx += x; cnt += 1.0f; }
       }
       sx = wave_sum(sx);
@@ -712,6 +732,199 @@ __global__ __launch_bounds__(256) void k_path_logprob(const float *scores, const
   if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) out[n] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+// ------------------------------------------------------------------ sequence scoring, backward
+// d out[n] / d scores[n, t, :] of nfst_path_logprob, times grad_out[n]: the reference trains p~
+// straight through evaluate_seq_with_temp (lightning.py:511-516).  With e = the masked, scaled
+// row, p = softmax(e), the per-row value is sel = sum_v td[v] * clamp(final[v]), final = e - lse
+// (normalize) or e; td = one-hot of the realised mark (evaluation) or the label-smoothed target
+// (scorers.py:1502-1528).  So
+//     d sel / d scores[u] = (tdc[u] - p[u] * W) * padmask[u] / temp,   tdc = td * clamp',  W = sum tdc
+// (W = 0 without the log_softmax); rows whose mark is pad contribute nothing; the pad column never
+// receives a gradient (pad_masking_3d multiplies it by zero; GPT2Wrapper overwrites it).  Same
+// streaming layout as the forward kernel: a row is recomputed in registers and its gradient row
+// is written with 16-byte stores -- N T V 4 bytes read, as many written.
+template <int NV, int RB, int L>
+__global__ __launch_bounds__(256) void k_path_logprob_bwd_v4(const float *__restrict__ scores,
+                                                             const int64_t *__restrict__ marks,
+                                                             const float *__restrict__ grad_out, int T, int V, int pad,
+                                                             int bos, int eos, int max_length, float temp, int normalize,
+                                                             float smoothing, int mode, float *__restrict__ grad) {
+  constexpr int HR = 64 / L;
+  const bool gpt2 = mode == 1;
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ll = lane & (L - 1), hsel = lane / L;
+  const int64_t *mk = marks + n * T;
+  const float rtemp = 1.0f / temp;
+  const float g = grad_out[n];
+  uint32_t m_norm = 0, m_end = 0, m_force = 0, m_pad = 0;
+  lane_masks<NV, L>(ll, V, pad, bos, eos, gpt2, m_norm, m_end, m_force, m_pad);
+  uint32_t m_padcol = 0;  // the pad column in either mode: no gradient
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((c * L + ll) * 4 + k == pad) m_padcol |= 1u << (c * 4 + k);
+  for (int t0 = wave * RB * HR; t0 < T; t0 += 4 * RB * HR) {
+    float4 v[RB][NV];
+    int lab[RB], prev[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int t = min(t0 + r * HR + hsel, T - 1);
+      const float4 *row = reinterpret_cast<const float4 *>(scores + ((size_t)n * T + t) * V);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const int q = c * L + ll;
+        v[r][c] = (4 * q < V) ? row[q] : make_float4(kNegInf, kNegInf, kNegInf, kNegInf);
+      }
+      lab[r] = (int)mk[t];
+      prev[r] = t > 0 ? (int)mk[t - 1] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      if (t0 + r * HR >= T) break;  // wave-uniform
+      const int t = min(t0 + r * HR + hsel, T - 1);
+      const bool valid = t0 + r * HR + hsel < T;
+      const bool first = t == 0;
+      const bool ended = !gpt2 && !first && (prev[r] == eos || prev[r] == pad);
+      const bool force = !gpt2 && !first && max_length >= 0 && t > max_length && !ended;
+      const uint32_t bad = ended ? m_end : (force ? m_force : m_norm);
+      float mx = kNegInf;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        float *e = reinterpret_cast<float *>(&v[r][c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x = ended ? 0.0f : ((m_pad & (1u << (c * 4 + k))) ? -1.0e8f * rtemp : e[k] * rtemp);
+          e[k] = (bad & (1u << (c * 4 + k))) ? kNegInf : x;
+          mx = fmaxf(mx, e[k]);
+        }
+      }
+      float lse = 0.0f, rsm = 0.0f;
+      if (normalize) {
+        mx = row_max<L>(mx);
+        float sm = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sm += __expf(e[k] - mx);
+        }
+        sm = row_sum<L>(sm);
+        lse = mx + logf(sm);
+        rsm = 1.0f / sm;
+      }
+      // the target's weights: realised mark / other legal marks
+      float w_lab = 1.0f, w_other = 0.0f;
+      if (smoothing > 0.0f) {
+        float cnt = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cnt += (e[k] - lse > kNegInf) ? 1.0f : 0.0f;
+        }
+        cnt = row_sum<L>(cnt);
+        w_lab = 1.0f - smoothing;
+        w_other = cnt > 1.0f ? smoothing / (cnt - 1.0f) : 0.0f;
+      }
+      // tdc and its row sum W
+      float tdc[NV][4];
+      float W = 0.0f;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const float *e = reinterpret_cast<const float *>(&v[r][c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = (c * L + ll) * 4 + k;
+          const float fin = e[k] - lse;  // -inf for masked columns (and for columns beyond V)
+          // the clamp's derivative (scorers.py:1591): 1 inside [-1e9, 1e9]; evaluation mode has no clamp,
+          // but a masked realised mark still passes its one-hot weight (d(-inf + x)/dx = 1)
+          const bool inside = smoothing > 0.0f ? (fin >= -10e8f && fin <= 10e8f) : true;
+          const float td = (col == lab[r]) ? w_lab : ((fin > kNegInf) ? w_other : 0.0f);
+          tdc[c][k] = (col < V && inside) ? td : 0.0f;
+          W += tdc[c][k];
+        }
+      }
+      W = normalize ? row_sum<L>(W) : 0.0f;
+      const float coef = (valid && lab[r] != pad) ? g * rtemp : 0.0f;
+      if (valid) {
+        float4 *orow = reinterpret_cast<float4 *>(grad + ((size_t)n * T + t) * V);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          const float *e = reinterpret_cast<const float *>(&v[r][c]);
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float p = normalize ? __expf(e[k] - mx) * rsm : 0.0f;
+            const float x = coef * (tdc[c][k] - p * W);
+            // a row without a contribution is all zeros (never NaN from an all-masked row)
+            o[k] = (coef == 0.0f || (m_padcol & (1u << (c * 4 + k)))) ? 0.0f : x;
+          }
+          const int q = c * L + ll;
+          if (4 * q < V) orow[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+  }
+}
+
+// scalar fallback (V % 4 != 0 or V > 1024): one wave per row, three passes over the row
+__global__ __launch_bounds__(256) void k_path_logprob_bwd(const float *scores, const int64_t *marks, const float *grad_out,
+                                                          int T, int V, int pad, int bos, int eos, int max_length,
+                                                          float temp, int normalize, float smoothing, int mode,
+                                                          float *grad) {
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t *mk = marks + n * T;
+  const bool gpt2 = mode == 1;
+  const float g = grad_out[n], rtemp = 1.0f / temp;
+  for (int t = wave; t < T; t += 4) {
+    const float *row = scores + ((size_t)n * T + t) * V;
+    float *orow = grad + ((size_t)n * T + t) * V;
+    const int prev = t > 0 ? (int)mk[t - 1] : -1;
+    const int lab = (int)mk[t];
+    const float coef = (lab != pad) ? g * rtemp : 0.0f;
+    if (coef == 0.0f) {
+      for (int v = lane; v < V; v += 64) orow[v] = 0.0f;
+      continue;
+    }
+    float mx = kNegInf, sm = 0.0f, cnt = 0.0f;
+    for (int v = lane; v < V; v += 64) {
+      const float x = seq_value(row, v, t, prev, pad, bos, eos, max_length, temp, gpt2);
+      mx = fmaxf(mx, x);
+      if (x > kNegInf) cnt += 1.0f;
+    }
+    mx = wave_max(mx);
+    cnt = wave_sum(cnt);
+    float lse = 0.0f, rsm = 0.0f;
+    if (normalize) {
+      for (int v = lane; v < V; v += 64) sm += __expf(seq_value(row, v, t, prev, pad, bos, eos, max_length, temp, gpt2) - mx);
+      sm = wave_sum(sm);
+      lse = mx + logf(sm);
+      rsm = 1.0f / sm;
+    }
+    const float w_lab = smoothing > 0.0f ? 1.0f - smoothing : 1.0f;
+    const float w_other = (smoothing > 0.0f && cnt > 1.0f) ? smoothing / (cnt - 1.0f) : 0.0f;
+    auto tdc_of = [&](int v, float x) {
+      const float fin = x - lse;
+      const bool inside = smoothing > 0.0f ? (fin >= -10e8f && fin <= 10e8f) : true;
+      const float td = (v == lab) ? w_lab : ((fin > kNegInf) ? w_other : 0.0f);
+      return inside ? td : 0.0f;
+    };
+    float W = 0.0f;
+    if (normalize) {
+      for (int v = lane; v < V; v += 64) W += tdc_of(v, seq_value(row, v, t, prev, pad, bos, eos, max_length, temp, gpt2));
+      W = wave_sum(W);
+    }
+    for (int v = lane; v < V; v += 64) {
+      const float x = seq_value(row, v, t, prev, pad, bos, eos, max_length, temp, gpt2);
+      const float p = normalize ? __expf(x - mx) * rsm : 0.0f;
+      orow[v] = (v == pad) ? 0.0f : coef * (tdc_of(v, x) - p * W);
+    }
+  }
 }
 
 __global__ void k_iwae(const float *log_p, const float *log_q, int B, int K, float *log_w,

@@ -369,12 +369,47 @@ def gather_label_scores(lat: LatticeBatch, theta, arc_scores=None) -> torch.Tens
     return out
 
 
+MASK_STATICRNN, MASK_GPT2 = 0, 1
+
+
+def _plp_args(pad, bos, eos, max_length, temp, normalize, smoothing, mask_mode):
+    return (int(pad), int(bos), int(eos), -1 if max_length is None else int(max_length), C.c_float(temp),
+            int(bool(normalize)), C.c_float(smoothing), int(mask_mode))
+
+
+class _PathLogprob(torch.autograd.Function):
+    """out[n] = sum_t (log_softmax row gathered / label-smoothed), d out / d scores by
+    nfst_path_logprob_backward (recomputes the rows; nothing but the inputs is saved)."""
+
+    @staticmethod
+    def forward(ctx, scores, marks, cfg):
+        N, T, V = scores.shape
+        out = torch.empty(N, dtype=torch.float32, device=scores.device)
+        check(lib.nfst_path_logprob(_ptr(scores), _ptr(marks), N, T, V, *_plp_args(*cfg), _ptr(out), _stream()),
+              "nfst_path_logprob")
+        ctx.cfg = cfg
+        ctx.save_for_backward(scores, marks)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        scores, marks = ctx.saved_tensors
+        N, T, V = scores.shape
+        g = g.to(torch.float32).contiguous()
+        grad = torch.empty_like(scores)
+        check(lib.nfst_path_logprob_backward(_ptr(scores), _ptr(marks), _ptr(g), N, T, V, *_plp_args(*ctx.cfg), _ptr(grad),
+                                             _stream()), "nfst_path_logprob_backward")
+        return grad, None, None
+
+
 def path_logprob(scores: torch.Tensor, marks: torch.Tensor, pad: int = 0, bos: int = 1, eos: int = 2,
                  max_length: Optional[int] = None, temp: float = 1.0, normalize: bool = True,
-                 smoothing: float = 0.0) -> torch.Tensor:
+                 smoothing: float = 0.0, mask_mode: int = MASK_STATICRNN) -> torch.Tensor:
     """Fused masks + log_softmax + gather + pad-masked sum over time
     (StaticRNNScorer.evaluate_seq_with_temp, scorers.py:1564-1611): scores [N,T,V], marks [N,T] -> [N].
-    ``smoothing > 0`` selects the training branch (label-smoothed target, scorers.py:1584-1592)."""
+    ``smoothing > 0`` selects the training branch (label-smoothed target, scorers.py:1584-1592).
+    Differentiable with respect to ``scores`` -- the reference trains p~ through this op
+    (lightning.py:511-516)."""
     if scores.device.type != "cuda":
         raise RuntimeError("nfst_amd: path_logprob runs on the MI355X only (no CPU fallback)")
     scores = scores.to(torch.float32).contiguous()
@@ -382,11 +417,19 @@ def path_logprob(scores: torch.Tensor, marks: torch.Tensor, pad: int = 0, bos: i
     N, T, V = scores.shape
     if marks.shape != (N, T):
         raise ValueError("marks must be [N, T]")
-    out = torch.empty(N, dtype=torch.float32, device=scores.device)
-    check(lib.nfst_path_logprob(_ptr(scores), _ptr(marks), N, T, V, int(pad), int(bos), int(eos),
-                                -1 if max_length is None else int(max_length), C.c_float(temp), int(bool(normalize)),
-                                C.c_float(smoothing), _ptr(out), _stream()), "nfst_path_logprob")
-    return out
+    return _PathLogprob.apply(scores, marks, (pad, bos, eos, max_length, temp, normalize, smoothing, mask_mode))
+
+
+def gpt2_logprob(logits: torch.Tensor, x: torch.Tensor, pad: int = 0) -> torch.Tensor:
+    """The arithmetic of ``GPT2Wrapper.forward`` after the language model (modules/transformer.py:45-52):
+    ``logits`` [N, T+1, V] are the model's outputs for the bos-shifted input ``cat(bos, x)``, ``x`` [N, T] the
+    marks; gold = ``cat(x, pad)``; the pad logit becomes -1e8, log_softmax, gather of gold, positions
+    holding pad contribute 0, sum over time -> [N].  Differentiable with respect to ``logits``."""
+    N, T = x.shape
+    if tuple(logits.shape[:2]) != (N, T + 1):
+        raise ValueError("logits must be [N, T + 1, V] for x [N, T]")
+    gold = torch.cat((x, x.new_full((N, 1), pad)), dim=1)
+    return path_logprob(logits, gold, pad=pad, normalize=True, mask_mode=MASK_GPT2)
 
 
 def iwae(log_p: torch.Tensor, log_q: torch.Tensor):

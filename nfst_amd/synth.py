@@ -281,6 +281,16 @@ def batch_arcs(lattices: Sequence[SynthLattice]):
     return n_rows, arc_off, src, label, dst, weight
 
 
+def snips_shaped_batch(n_lattices: int = 64, vocab: int = 250, first_seed: int = 3000) -> List[SynthLattice]:
+    """BASELINE configs[2]-shaped lattices: tagging machines are long and narrow -- a few tag states
+    per token position, up to ~750 positions (S ~ 400..1500, V ~ 250).  (The real SNIPS machines are
+    built with mfst / OpenFST, which this image does not have: SURVEY.md section 8c.)"""
+    rng = np.random.default_rng(64)
+    return [layered_lattice(first_seed + i, n_states=int(rng.integers(400, 1501)), avg_degree=float(rng.choice([3.0, 5.0, 8.0])),
+                            vocab=vocab, width=int(rng.choice([2, 3, 6, 8])), span=int(rng.choice([1, 2])), max_degree=40)
+            for i in range(n_lattices)]
+
+
 def without_parallel_arcs(l: SynthLattice) -> SynthLattice:
     """The lattice with one arc kept per (src, dst) pair (the one with the smallest label): the
     reference's ``compute_beta_parallel`` never releases a state with two arcs to the same

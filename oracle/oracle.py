@@ -327,6 +327,66 @@ def evaluate_seq(scores: np.ndarray, seqs: np.ndarray, pad: int, bos: int, eos: 
     return sel.sum(axis=1)
 
 
+def evaluate_seq_grad(scores: np.ndarray, seqs: np.ndarray, g: np.ndarray, pad: int, bos: int, eos: int, max_length: int,
+                      temp: float = 1.0, normalize: bool = True, training: bool = False, smoothing: float = 0.0) -> np.ndarray:
+    """d (sum_n g[n] evaluate_seq(...)[n]) / d scores, float64 -- what torch.autograd gives through
+    scorers.py:1564-1611: with e = (scores * padmask + mask) / temp + mask, final = log_softmax(e) or e,
+    value = sum_v td[v] clamp(final[v]) per row (td: one-hot, or the smoothed target of 1502-1528),
+        d value / d scores[u] = (td[u] c'[u] - softmax(e)[u] * sum_v td[v] c'[v]) * padmask[u] / temp
+    (the softmax term only with the log_softmax; c' = the clamp's derivative)."""
+    N, T, V = scores.shape
+    mask = batched_seq_mask(seqs, V, pad, bos, eos, max_length).astype(np.float64)
+    pz = np.ones(V); pz[pad] = 0
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        e = (scores.astype(np.float64) * pz[None, None, :] + mask) / temp + mask
+        if normalize:
+            m = e.max(axis=2, keepdims=True)
+            lse = m + np.log(np.exp(e - m).sum(axis=2, keepdims=True))
+            final = e - lse
+            p = np.exp(final)
+        else:
+            final = e
+            p = np.zeros_like(e)
+        lab = seqs.reshape(-1)
+        flat = final.reshape(-1, V)
+        rows = np.arange(flat.shape[0])
+        if training:
+            finite = flat > -np.inf
+            cnt = finite.sum(axis=1, keepdims=True).astype(np.float64)
+            td = np.where(finite, smoothing / (cnt - 1), 0.0) * np.ones_like(flat)
+            td[rows, lab] = 1.0 - smoothing
+            td = td * ((flat >= -10e8) & (flat <= 10e8))
+        else:
+            td = np.zeros_like(flat)
+            td[rows, lab] = 1.0
+        W = td.sum(axis=1, keepdims=True) if normalize else 0.0
+        d = (td - p.reshape(-1, V) * W).reshape(N, T, V)
+        d = d * pz[None, None, :] / temp
+        d = d * ((seqs != pad)[:, :, None]) * g.astype(np.float64)[:, None, None]
+    return d
+
+
+def gpt2_logprob(logits: np.ndarray, x: np.ndarray, pad: int, g: Optional[np.ndarray] = None):
+    """GPT2Wrapper.forward after the language model (transformer.py:38-52): gold = cat(x, pad), the pad
+    logit becomes -1e8, log_softmax, gather, positions holding pad contribute 0, sum over time.
+    With ``g`` also d (sum_n g[n] value[n]) / d logits (the overwritten pad column gets none)."""
+    N, T1, V = logits.shape
+    gold = np.concatenate([x, np.full((N, 1), pad, x.dtype)], axis=1)
+    lg = logits.astype(np.float64).copy()
+    lg[:, :, pad] = -1e8
+    m = lg.max(axis=2, keepdims=True)
+    lp = lg - (m + np.log(np.exp(lg - m).sum(axis=2, keepdims=True)))
+    keep = gold != pad
+    val = (np.take_along_axis(lp, gold[:, :, None], axis=2)[:, :, 0] * keep).sum(axis=1)
+    if g is None:
+        return val
+    onehot = np.zeros_like(lp)
+    np.put_along_axis(onehot, gold[:, :, None], 1.0, axis=2)
+    d = (onehot - np.exp(lp)) * keep[:, :, None] * g.astype(np.float64)[:, None, None]
+    d[:, :, pad] = 0.0
+    return val, d
+
+
 def proposal_step(emission_k: np.ndarray, transition_k: np.ndarray, scores: np.ndarray, inp: np.ndarray,
                   state: np.ndarray, length: int, max_length: int, pad: int, bos: int, eos: int,
                   temperature: float = 1.0, beta: Optional[np.ndarray] = None, uniforms: Optional[np.ndarray] = None,

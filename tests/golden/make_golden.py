@@ -28,6 +28,12 @@ What is pinned (reference file:line):
   evalseq.npz    StaticRNNScorer.evaluate_seq_with_temp arithmetic
                  (scorers.py:1530-1614, masks 89-134, smoothing 1502-1528) on
                  supplied score tensors (the RNN itself is out of scope).
+  evalseq_grad.npz  the same function's gradient with respect to the supplied scores
+                 (torch.autograd through the reference's code; lightning.py:511-516
+                 trains p~ through it).
+  gpt2.npz       GPT2Wrapper.forward (transformer.py:34-52) on supplied logits: value
+                 and gradient.
+  strip.npz      Sampler.stripping_pad (samplers.py:162-180) with pad = 0 and pad = 7.
 """
 import os
 import sys
@@ -361,8 +367,106 @@ def make_evalseq():
     save("evalseq.npz", **out)
 
 
+def make_evalseq_grad():
+    """Gradients of evaluate_seq_with_temp with respect to the supplied scores (the reference trains
+    p~ through it, lightning.py:511-516): d (sum_n g[n] * value[n]) / d scores by torch.autograd on the
+    reference's own code.  V = 20 (16-byte streaming kernels) and V = 22 (scalar fallback)."""
+    out = {}
+    for V in (20, 22):
+        N, T = 6, 9
+        rng = np.random.default_rng(80 + V)
+        seqs = np.full((N, T), PAD, dtype=np.int64)
+        for n in range(N):
+            L = int(rng.integers(2, 6))  # within max_length = 5 of the "short" case
+            seqs[n, :L] = rng.integers(3, V, size=L)
+            seqs[n, L] = EOS
+        scores = rng.normal(0, 1.5, size=(N, T, V)).astype(np.float32)
+        g = rng.normal(0, 1.0, size=N).astype(np.float32)
+        out.update({f"v{V}_seqs": seqs, f"v{V}_scores": scores, f"v{V}_g": g})
+        for tag, (maxlen, norm, smooth, training, temp) in {
+            "norm_eval": (30, True, 0.0, False, 1.0),
+            "norm_eval_temp": (30, True, 0.0, False, 0.7),
+            "norm_eval_short": (5, True, 0.0, False, 1.0),
+            "raw_eval": (30, False, 0.0, False, 1.0),
+            "norm_train_smooth": (30, True, 0.1, True, 1.0),
+            "norm_train_smooth_temp": (30, True, 0.25, True, 1.3),
+            "raw_train_smooth": (30, False, 0.2, True, 0.8),
+        }.items():
+            pr = _GatherProbe(V, maxlen, norm, smooth)
+            pr.train(training)
+            sc = torch.from_numpy(scores).clone().requires_grad_(True)
+            pr._scores = sc
+            val = pr.evaluate_seq_with_temp(torch.from_numpy(seqs), temp=temp)
+            (val * torch.from_numpy(g)).sum().backward()
+            assert torch.isfinite(val).all() and torch.isfinite(sc.grad).all()
+            out[f"v{V}_{tag}"] = val.detach().numpy().astype(np.float32)
+            out[f"v{V}_{tag}_grad"] = sc.grad.numpy().astype(np.float32)
+            out[f"v{V}_{tag}_cfg"] = np.array([maxlen, int(norm), smooth, int(training), temp], dtype=np.float64)
+    save("evalseq_grad.npz", **out)
+
+
+def make_gpt2():
+    """GPT2Wrapper.forward (transformer.py:34-52) on supplied logits: the language model inside the
+    wrapper is replaced by a stub that returns the supplied tensor; the pad logit overwrite, the
+    log_softmax, the gather of the shifted gold sequence, the pad mask and the sum are the reference's
+    own code.  Values and d (sum_n g[n] value[n]) / d logits."""
+    from types import SimpleNamespace
+    from src.modules.transformer import GPT2Wrapper
+
+    class _Stub(torch.nn.Module):
+        def forward(self, inp):
+            assert tuple(inp.shape) == tuple(self.logits.shape[:2])
+            return SimpleNamespace(logits=self.logits * 1.0)  # not a leaf: the wrapper writes into it
+
+    out = {}
+    for V in (20, 22, 300):
+        N, T = 5, 8
+        rng = np.random.default_rng(90 + V)
+        x = np.full((N, T), PAD, dtype=np.int64)
+        for n in range(N):
+            L = int(rng.integers(2, T))
+            x[n, :L] = rng.integers(3, V, size=L)
+            x[n, L] = EOS
+        x[0, :] = rng.integers(3, V, size=T)  # a full row: its only pad is the appended one
+        logits = rng.normal(0, 2.0, size=(N, T + 1, V)).astype(np.float32)
+        g = rng.normal(0, 1.0, size=N).astype(np.float32)
+        # the constructor only builds the Hugging Face model (and its positional GPT2Config call is
+        # rejected by the transformers version installed here): the attributes forward() reads are set
+        # by hand, forward() itself is the reference's
+        w = GPT2Wrapper.__new__(GPT2Wrapper)
+        torch.nn.Module.__init__(w)
+        w.vocab_size, w.bos, w.eos, w.pad, w.max_length = V, BOS, EOS, PAD, T + 1
+        w.model = _Stub()
+        lg = torch.from_numpy(logits).clone().requires_grad_(True)
+        w.model.logits = lg
+        val = w(torch.from_numpy(x))
+        (val * torch.from_numpy(g)).sum().backward()
+        out.update({f"v{V}_x": x, f"v{V}_logits": logits, f"v{V}_g": g, f"v{V}_value": val.detach().numpy().astype(np.float32),
+                    f"v{V}_grad": lg.grad.numpy().astype(np.float32)})
+    save("gpt2.npz", **out)
+
+
+def make_strip():
+    """Sampler.stripping_pad (samplers.py:162-180) with pad != 0: marks equal to 0 are dropped, pad marks
+    are kept, and a row that ends in a dropped 0 keeps one 0 after its last mark."""
+    from types import SimpleNamespace
+    out = {}
+    rng = np.random.default_rng(21)
+    for pad in (0, 7):
+        smp = Sampler.__new__(Sampler)
+        smp.model = SimpleNamespace(__pad__=pad)
+        seqs = rng.integers(0, 10, size=(12, 14)).astype(np.int64)
+        seqs[rng.random(seqs.shape) < 0.25] = 0
+        for n in range(12):
+            seqs[n, int(rng.integers(5, 12)):] = pad  # pad tail; column 11 onwards is pad everywhere
+        out[f"pad{pad}_in"] = seqs
+        out[f"pad{pad}_out"] = smp.stripping_pad(torch.from_numpy(seqs)).numpy()
+    save("strip.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py make_beta_neural`; nothing = all
-    for fn in (make_beta, make_beta_neural, make_gather, make_sampler_and_iwae, make_evalseq):
+    for fn in (make_beta, make_beta_neural, make_gather, make_sampler_and_iwae, make_evalseq, make_evalseq_grad, make_gpt2,
+               make_strip):
         if not only or fn.__name__ in only:
             fn()

@@ -1,8 +1,10 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the golden
 fixtures.  Needs a real MI355X: run with ``pytest -m gpu``.
 
-Tolerances: log Z, log alpha, log beta <= 1e-5 absolute (north_star); posteriors
-<= 2e-6 absolute; state / arc / label indices bit-exact."""
+Tolerances: log Z (float64 output) <= 1e-5 absolute everywhere (north_star); the float32 row
+outputs log alpha / log beta <= 1e-5 + half a float32 spacing at their magnitude; posteriors
+<= 2e-6 absolute at the BASELINE depth (<= 1e-5 for 1500-level lattices); state / arc / label
+indices bit-exact.  The largest errors seen are written to gpurun_out/parity_errors.json."""
 import os
 
 import numpy as np
@@ -22,6 +24,27 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
+# largest errors seen per check, written to gpurun_out/parity_errors.json at the end of the module
+# (DESIGN.md section 5 quotes them)
+_ERR = {}
+
+
+def rec(tag, err):
+    err = float(err)
+    _ERR[tag] = max(_ERR.get(tag, 0.0), err)
+    return err
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_errors():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if _ERR and os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(dict(sorted(_ERR.items())), f, indent=1)
+
+
 def oracle_fb(l, theta, arc_scores=None):
     sc = theta[l.label].astype(np.float64)
     if l.weight is not None:
@@ -31,11 +54,20 @@ def oracle_fb(l, theta, arc_scores=None):
     return O.forward_backward(l.n_rows, l.src, l.dst, sc), sc
 
 
-def cmp_rows(got, ref, tol=TOL):
+def cmp_rows(got, ref, tol=TOL, tag=None):
+    """Row outputs (log alpha, log beta) are float32: beside `tol` they may be off by the rounding
+    of the exact value to float32, half a float32 spacing at its magnitude (3e-5 at |log beta| = 600;
+    the (mantissa, exponent) pairs `beta_me` carry the full precision).  log Z is checked in float64
+    at the plain `tol`."""
     got = np.asarray(got, np.float64)
     inf = np.isneginf(ref)
     assert np.array_equal(np.isneginf(got), inf)
-    assert np.max(np.abs(got[~inf] - ref[~inf])) <= tol
+    err = np.abs(got[~inf] - ref[~inf])
+    half_ulp = 0.5 * np.spacing(np.abs(ref[~inf]).astype(np.float32)).astype(np.float64)
+    if tag:
+        rec(tag, err.max())
+        rec(tag + "_beyond_f32_rounding", np.maximum(err - half_ulp, 0.0).max())
+    assert np.all(err <= tol + half_ulp)
 
 
 # ----------------------------------------------------------------------------- golden fixtures
@@ -176,8 +208,8 @@ def test_extreme_scores_do_not_overflow(dev):
         r = ops.forward_backward(lat, torch.from_numpy(theta))
         o, _ = oracle_fb(l, theta)
         assert abs(o["logZ"]) > 200
-        assert abs(float(r.logz64[0]) - o["logZ"]) <= 1e-5 * max(1.0, abs(o["logZ"]) / 16)
-        assert np.max(np.abs(r.posterior.cpu().numpy() - o["posterior"])) <= 5e-6
+        assert rec("extreme_scores_logz", abs(float(r.logz64[0]) - o["logZ"])) <= TOL  # |log Z| > 200, absolute
+        assert rec("extreme_scores_post", np.max(np.abs(r.posterior.cpu().numpy() - o["posterior"]))) <= 5e-6
     # a forbidden label (-inf) removes its arcs
     theta = synth.label_scores(3, 64)
     theta[l.label[5]] = -np.inf
@@ -321,10 +353,10 @@ def test_baseline_batch_properties_and_oracle(dev):
     r = ops.forward_backward(lat, torch.from_numpy(theta))
     n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lats)
     zref, pref = O.forward_backward_batch(n_rows, arc_off, src, label, dst, None, theta, n_threads=8)
-    assert np.max(np.abs(r.logz64.cpu().numpy() - zref)) <= TOL
-    assert np.max(np.abs(r.logz.cpu().numpy() - zref)) <= TOL
+    assert rec("baseline_logz64", np.max(np.abs(r.logz64.cpu().numpy() - zref))) <= TOL
+    assert rec("baseline_logz32", np.max(np.abs(r.logz.cpu().numpy() - zref))) <= TOL
     post = r.posterior.cpu().numpy().astype(np.float64)
-    assert np.max(np.abs(post - pref)) <= 2e-6
+    assert rec("baseline_post", np.max(np.abs(post - pref))) <= 2e-6
     la = r.logalpha.cpu().numpy()
     # size-independent identities: Z from alpha == Z from beta; unit flow out of the start and
     # into the sink; flow conservation at every inner state
@@ -343,6 +375,60 @@ def test_baseline_batch_properties_and_oracle(dev):
     # run-to-run determinism of everything but the LDS label histogram
     r2 = ops.forward_backward(lat, torch.from_numpy(theta))
     assert torch.equal(r.posterior, r2.posterior) and torch.equal(r.logz64, r2.logz64)
+
+
+def test_configs3_shard_1024_lattices(dev):
+    """BASELINE.json configs[3]: 8192 lattices over 8 GPUs = one shard of 1024 x (~2k states /
+    ~20k arcs) per GPU.  More lattices than 2 x CUs: the 256-thread flavour (two workgroups per CU,
+    self-loading decoders).  Oracle (float64) on every 16th lattice at the strict 1e-5 / 2e-6; the
+    size-independent flow identities on all of them; and the first 256 / 512 lattices must come out
+    with the bits of the 1024-thread (one lattice per CU) and 512-thread flavours."""
+    B = 1024
+    lats = synth.bench_batch(B)
+    theta_np = synth.label_scores(1, 256)
+    theta = torch.from_numpy(theta_np).to(dev)
+    quarters = [LatticeBatch.from_synth(lats[i:i + 256]) for i in range(0, B, 256)]  # packed once per quarter ...
+    lat = LatticeBatch.concat(quarters, device=dev)  # ... the shard by concatenation (bit-identical to packing it whole)
+    assert lat.n_lattices == B and 18e6 < lat.total_arcs < 23e6
+    r = ops.forward_backward(lat, theta)
+    z64, z32 = r.logz64.cpu().numpy(), r.logz.cpu().numpy()
+    post = r.posterior.cpu().numpy()
+    sample = list(range(0, B, 16))
+    n_rows, arc_off, src, label, dst, w = synth.batch_arcs([lats[i] for i in sample])
+    zref, pref = O.forward_backward_batch(n_rows, arc_off, src, label, dst, None, theta_np, n_threads=8)
+    assert rec("configs3_logz64", np.max(np.abs(z64[sample] - zref))) <= TOL
+    assert rec("configs3_logz32", np.max(np.abs(z32[sample] - zref))) <= TOL
+    for j, b in enumerate(sample):
+        a0 = int(lat.arc_off[b])
+        got = post[a0:a0 + lats[b].n_arcs].astype(np.float64)
+        assert rec("configs3_post", np.max(np.abs(got - pref[arc_off[j]:arc_off[j + 1]]))) <= 2e-6
+    # identities on all 1024: Z from alpha == Z from beta; unit flow out of the start and into the
+    # sink; flow conservation at every inner state
+    la = r.logalpha.cpu().numpy()
+    sink_rows = lat.row_off + lat.sink
+    assert rec("configs3_z_alpha_vs_beta", np.max(np.abs(la[sink_rows] - z32))) <= TOL
+    gsrc = lat.arc_src.cpu().numpy().astype(np.int64)
+    gdst = lat.arc_dst.cpu().numpy().astype(np.int64)
+    off = np.repeat(lat.row_off.astype(np.int64), lat.n_arcs)
+    nl = gsrc != gdst
+    p64 = post.astype(np.float64)
+    outflow = np.bincount((gsrc + off)[nl], weights=p64[nl], minlength=lat.total_rows)
+    inflow = np.bincount((gdst + off)[nl], weights=p64[nl], minlength=lat.total_rows)
+    assert np.max(np.abs(outflow[lat.row_off] - 1.0)) <= 2e-5
+    assert np.max(np.abs(inflow[sink_rows] - 1.0)) <= 2e-5
+    inner = np.ones(lat.total_rows, bool); inner[lat.row_off] = False; inner[sink_rows] = False
+    assert rec("configs3_flow_conservation", np.max(np.abs(inflow[inner] - outflow[inner]))) <= 2e-5
+    # flavours: 256 lattices -> 1024 threads, 512 -> 512 threads, 1024 -> 256 threads: same bits
+    for n in (256, 512):
+        part = LatticeBatch.concat(quarters[: n // 256], device=dev)
+        rp = ops.forward_backward(part, theta)
+        A, R = part.total_arcs, part.total_rows
+        assert torch.equal(rp.logz64, r.logz64[:n]) and torch.equal(rp.posterior, r.posterior[:A])
+        assert torch.equal(rp.logalpha, r.logalpha[:R]) and torch.equal(rp.logbeta, r.logbeta[:R])
+    # the fused loss of the shard
+    total = torch.zeros(3, dtype=torch.float64, device=dev)
+    ops.forward_backward(lat, theta, out=r, total=total, total_slot=0)
+    assert abs(float(total[0]) - float(r.logz64.sum())) <= 1e-9 * abs(float(r.logz64.sum()))
 
 
 @pytest.mark.parametrize("V,T", [(300, 37), (1000, 11), (301, 9), (64, 300), (100, 33), (128, 16), (256, 19), (384, 40),
@@ -370,6 +456,74 @@ def test_path_logprob_matches_oracle_all_variants(dev, V, T):
         assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
         assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) <= 2e-5
 
+GRAD_TAGS = ["norm_eval", "norm_eval_temp", "norm_eval_short", "raw_eval", "norm_train_smooth", "norm_train_smooth_temp",
+             "raw_train_smooth"]
+
+
+@pytest.mark.parametrize("V", [20, 22])
+@pytest.mark.parametrize("tag", GRAD_TAGS)
+def test_path_logprob_backward_fixture(dev, golden_dir, V, tag):
+    """Value and gradient of evaluate_seq_with_temp as torch.autograd gives them through the reference's
+    own code (scorers.py:1564-1611; lightning.py:511-516 trains p~ through it).  V = 20: the 16-byte
+    streaming kernels, V = 22: the scalar fallback."""
+    d = load(golden_dir, "evalseq_grad")
+    maxlen, norm, smooth, training, temp = d[f"v{V}_{tag}_cfg"]
+    sc = torch.from_numpy(d[f"v{V}_scores"]).to(dev).requires_grad_(True)
+    val = ops.path_logprob(sc, torch.from_numpy(d[f"v{V}_seqs"]).to(dev), pad=PAD, bos=BOS, eos=EOS, max_length=int(maxlen),
+                           temp=float(temp), normalize=bool(norm), smoothing=float(smooth) if training else 0.0)
+    (val * torch.from_numpy(d[f"v{V}_g"]).to(dev)).sum().backward()
+    ref_v, ref_g = d[f"v{V}_{tag}"], d[f"v{V}_{tag}_grad"]
+    assert np.max(np.abs(val.detach().cpu().numpy() - ref_v) / np.maximum(1.0, np.abs(ref_v))) <= 2e-5
+    assert rec("path_logprob_grad_fixture", np.max(np.abs(sc.grad.cpu().numpy() - ref_g) / np.maximum(1.0, np.abs(ref_g)))) <= 2e-5
+
+
+@pytest.mark.parametrize("V", [20, 22, 300])
+def test_gpt2_logprob_fixture(dev, golden_dir, V):
+    """GPT2Wrapper.forward on supplied logits (transformer.py:38-52): pad logit -1e8, no legality masks,
+    gold shifted with a trailing pad; value and gradient produced by the reference."""
+    d = load(golden_dir, "gpt2")
+    lg = torch.from_numpy(d[f"v{V}_logits"]).to(dev).requires_grad_(True)
+    val = ops.gpt2_logprob(lg, torch.from_numpy(d[f"v{V}_x"]).to(dev), pad=PAD)
+    (val * torch.from_numpy(d[f"v{V}_g"]).to(dev)).sum().backward()
+    ref_v, ref_g = d[f"v{V}_value"], d[f"v{V}_grad"]
+    assert np.max(np.abs(val.detach().cpu().numpy() - ref_v) / np.maximum(1.0, np.abs(ref_v))) <= 2e-5
+    assert np.max(np.abs(lg.grad.cpu().numpy() - ref_g)) <= 2e-5
+
+
+@pytest.mark.parametrize("V,T", [(300, 37), (1000, 11), (301, 9), (64, 40), (100, 33), (128, 16), (256, 19), (384, 40),
+                                 (500, 10), (600, 21), (36, 9), (180, 23), (440, 13), (700, 9), (900, 5), (1024, 6), (1028, 4)])
+def test_path_logprob_backward_matches_oracle_all_variants(dev, V, T):
+    """Every kernel variant of the backward pass against the float64 restatement (pinned by the
+    fixtures above): evaluation, temperature, short max_length, raw scores, label smoothing; GPT2 mode."""
+    rng = np.random.default_rng(1000 + V)
+    N = 5
+    seqs = np.full((N, T), PAD, dtype=np.int64)
+    for n in range(N):
+        L = int(rng.integers(2, T - 1))
+        seqs[n, :L] = rng.integers(3, V, size=L)
+        seqs[n, L] = EOS
+    scores = rng.normal(0, 2.0, size=(N, T, V)).astype(np.float32)
+    g = rng.normal(0, 1.0, size=N).astype(np.float32)
+    tsc, tseq, tg = torch.from_numpy(scores).to(dev), torch.from_numpy(seqs).to(dev), torch.from_numpy(g).to(dev)
+    for norm, temp, maxlen, smooth in ((True, 1.0, 1000, 0.0), (True, 0.6, 1000, 0.0), (False, 1.0, 1000, 0.0),
+                                       (True, 1.0, T, 0.0), (True, 1.0, 1000, 0.1), (False, 0.8, 1000, 0.2)):
+        ref = O.evaluate_seq_grad(scores, seqs, g, PAD, BOS, EOS, maxlen, temp=temp, normalize=norm, training=smooth > 0,
+                                  smoothing=smooth)
+        sc = tsc.clone().requires_grad_(True)
+        val = ops.path_logprob(sc, tseq, pad=PAD, bos=BOS, eos=EOS, max_length=maxlen, temp=temp, normalize=norm, smoothing=smooth)
+        (val * tg).sum().backward()
+        got = sc.grad.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(got))
+        assert rec("path_logprob_grad_oracle", np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))) <= 2e-5
+    x = seqs[:, :-1]
+    refv, refg = O.gpt2_logprob(scores, x, PAD, g)
+    lg = tsc.clone().requires_grad_(True)
+    val = ops.gpt2_logprob(lg, torch.from_numpy(x).to(dev), pad=PAD)
+    (val * tg).sum().backward()
+    assert np.max(np.abs(val.detach().cpu().numpy() - refv) / np.maximum(1.0, np.abs(refv))) <= 2e-5
+    assert np.max(np.abs(lg.grad.cpu().numpy() - refg)) <= 2e-5
+
+
 def test_large_lattice_falls_back_to_small_rings(dev):
     """A lattice close to the LDS limit (alpha + beta = 16 B per state of the CU's 160 KiB) leaves
     room for the smallest rings only (3 decoded + 5 staging slots, self-loading decoder)."""
@@ -384,10 +538,10 @@ def test_large_lattice_falls_back_to_small_rings(dev):
     for b, l in enumerate([big, small]):
         o, _ = oracle_fb(l, theta)
         r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
-        assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL * max(1.0, abs(o["logZ"]) / 16)
-        assert abs(float(rb.logz64[b]) - o["logZ"]) <= TOL * max(1.0, abs(o["logZ"]) / 16)
-        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tol=TOL * max(1.0, abs(o["logZ"]) / 16))
-        assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 5e-6
+        assert rec("large_lattice_logz", abs(float(r.logz64[b]) - o["logZ"])) <= TOL
+        assert abs(float(rb.logz64[b]) - o["logZ"]) <= TOL
+        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tag="large_lattice_logbeta")
+        assert rec("large_lattice_post", np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"]))) <= 5e-6
     # beyond the limit the launch is refused with an error code, not a fault
     huge = synth.layered_lattice(6, n_states=8180, avg_degree=4.0, vocab=V, width=32, span=4)
     lat = LatticeBatch.from_synth([huge], device=dev)
@@ -435,14 +589,13 @@ def test_random_shapes_match_oracle(dev, seed):
         la, lb, post = r.logalpha.cpu().numpy(), r.logbeta.cpu().numpy(), r.posterior.cpu().numpy()
         for b, l in enumerate(lats):
             o, _ = oracle_fb(l, theta)
-            tol = TOL * max(1.0, abs(o["logZ"]) / 16)
             r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
-            assert abs(float(r.logz64[b]) - o["logZ"]) <= tol
-            cmp_rows(la[r0:r0 + l.n_rows], o["logalpha"], tol)
-            cmp_rows(lb[r0:r0 + l.n_rows], o["logbeta"], tol)
+            assert rec("random_shapes_logz", abs(float(r.logz64[b]) - o["logZ"])) <= TOL
+            cmp_rows(la[r0:r0 + l.n_rows], o["logalpha"], tag="random_shapes_logalpha")
+            cmp_rows(lb[r0:r0 + l.n_rows], o["logbeta"], tag="random_shapes_logbeta")
             # float32 rounding accumulates over the levels (up to 1500 here): 1e-5 instead of the
             # 2e-6 that holds at the BASELINE depth
-            assert np.max(np.abs(post[a0:a0 + l.n_arcs] - o["posterior"])) <= 1e-5
+            assert rec("random_shapes_post", np.max(np.abs(post[a0:a0 + l.n_arcs] - o["posterior"]))) <= 1e-5
 
 
 def test_many_small_lattices_share_compute_units(dev):
@@ -525,7 +678,7 @@ def test_large_vocabulary_uses_32_bit_records(dev):
     for b, l in enumerate(lats):
         o, _ = oracle_fb(l, theta)
         a0 = int(lat.arc_off[b])
-        assert abs(float(r.logz64[b]) - o["logZ"]) <= TOL * max(1.0, abs(o["logZ"]) / 16)
+        assert rec("large_vocab_logz", abs(float(r.logz64[b]) - o["logZ"])) <= TOL
         assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
         best, path, arcs = O.viterbi(l.n_rows, l.src, l.label, l.dst, theta[l.label], 4000)
         n = int(v.lengths[b])
@@ -553,10 +706,7 @@ def test_snips_shaped_batch(dev):
     """BASELINE configs[2]: a batch of 64 tagging-shaped lattices (S ~ 400..1500, V ~ 250, long and
     narrow: a few tag states per token position, up to ~750 positions)."""
     V = 250
-    rng = np.random.default_rng(64)
-    lats = [synth.layered_lattice(3000 + i, n_states=int(rng.integers(400, 1501)), avg_degree=float(rng.choice([3.0, 5.0, 8.0])),
-                                  vocab=V, width=int(rng.choice([2, 3, 6, 8])), span=int(rng.choice([1, 2])), max_degree=40)
-            for i in range(64)]
+    lats = synth.snips_shaped_batch(64, vocab=V)
     theta = synth.label_scores(64, V, mean=-1.5, std=0.8)
     lat = LatticeBatch.from_synth(lats, device=dev)
     assert int(lat.depth.max()) >= 500
@@ -566,10 +716,9 @@ def test_snips_shaped_batch(dev):
         l = lats[b]
         o, _ = oracle_fb(l, theta)
         r0, a0 = int(lat.row_off[b]), int(lat.arc_off[b])
-        tol = TOL * max(1.0, abs(o["logZ"]) / 16)
-        assert abs(float(r.logz64[b]) - o["logZ"]) <= tol
-        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tol)
-        assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 1e-5
+        assert rec("snips_shaped_logz", abs(float(r.logz64[b]) - o["logZ"])) <= TOL  # configs[2]: 1e-5 absolute
+        cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tag="snips_shaped_logbeta")
+        assert rec("snips_shaped_post", np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"]))) <= 1e-5
         best, path, arcs = O.viterbi(l.n_rows, l.src, l.label, l.dst, theta[l.label], 4000)
         n = int(v.lengths[b])
         assert n == len(path) and np.float32(best) == v.best.cpu().numpy()[b]

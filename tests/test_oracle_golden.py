@@ -218,3 +218,36 @@ def test_beta_neural_matches_reference(golden_dir, name):
     np.testing.assert_allclose(par, c["beta_parallel"], rtol=2e-5, atol=1e-30)
     if name == "neural_edit_h8":  # no state pair with two labels: parallel == per-sample
         np.testing.assert_allclose(c["beta_parallel"], ref, rtol=2e-5)
+
+
+GRAD_TAGS = ["norm_eval", "norm_eval_temp", "norm_eval_short", "raw_eval", "norm_train_smooth", "norm_train_smooth_temp",
+             "raw_train_smooth"]
+
+
+@pytest.mark.parametrize("V", [20, 22])
+@pytest.mark.parametrize("tag", GRAD_TAGS)
+def test_evaluate_seq_gradient_matches_reference_autograd(golden_dir, V, tag):
+    """torch.autograd through the reference's evaluate_seq_with_temp (scorers.py:1564-1611)."""
+    d = load(golden_dir, "evalseq_grad")
+    maxlen, norm, smooth, training, temp = d[f"v{V}_{tag}_cfg"]
+    kw = dict(temp=float(temp), normalize=bool(norm), training=bool(training), smoothing=float(smooth))
+    val = O.evaluate_seq(d[f"v{V}_scores"], d[f"v{V}_seqs"], PAD, BOS, EOS, int(maxlen), **kw)
+    assert np.max(np.abs(val - d[f"v{V}_{tag}"])) <= 2e-5
+    grad = O.evaluate_seq_grad(d[f"v{V}_scores"], d[f"v{V}_seqs"], d[f"v{V}_g"], PAD, BOS, EOS, int(maxlen), **kw)
+    assert np.max(np.abs(grad - d[f"v{V}_{tag}_grad"])) <= 2e-6
+    assert np.any(grad != 0)
+
+
+@pytest.mark.parametrize("V", [20, 22, 300])
+def test_gpt2_wrapper_arithmetic(golden_dir, V):
+    """GPT2Wrapper.forward on supplied logits (transformer.py:38-52): value and gradient."""
+    d = load(golden_dir, "gpt2")
+    val, grad = O.gpt2_logprob(d[f"v{V}_logits"], d[f"v{V}_x"], PAD, d[f"v{V}_g"])
+    assert np.max(np.abs(val - d[f"v{V}_value"]) / np.maximum(1.0, np.abs(d[f"v{V}_value"]))) <= 2e-6
+    assert np.max(np.abs(grad - d[f"v{V}_grad"])) <= 2e-6
+
+
+@pytest.mark.parametrize("pad", [0, 7])
+def test_stripping_pad_fixture(golden_dir, pad):
+    d = load(golden_dir, "strip")
+    assert np.array_equal(O.stripping_pad(d[f"pad{pad}_in"], pad), d[f"pad{pad}_out"])

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in nfst_hip.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib.nfst_abi_version() == 3
+    assert _lib.lib.nfst_abi_version() == _lib.header_abi_version() == _lib.ABI_VERSION
 
 
 def test_ops_fail_loudly_without_gpu():
