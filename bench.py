@@ -95,6 +95,25 @@ def pmc_traffic_bytes():
         return None, None
 
 
+def host_cores() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    can show 256 logical CPUs to a job that owns a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(lats, theta, budget_s=12.0):
     """The oracle (a port of the reference's path-sum semantics, float64) timed on
     the host cores over the same lattices; repeated until ~budget_s of work."""
@@ -102,7 +121,7 @@ def cpu_baseline(lats, theta, budget_s=12.0):
     from oracle import oracle as O
     from nfst_amd import synth
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lats)
     dp = int((src != dst).sum())
     O.forward_backward_batch(n_rows, arc_off, src, label, dst, w, theta, n_threads=cores)  # warm-up
@@ -113,7 +132,7 @@ def cpu_baseline(lats, theta, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or reps >= 200:
             break
-    out = {"value": dp * reps / dt, "unit": "lattice-arcs/s", "cores": cores, "kind": "port",
+    out = {"value": dp * reps / dt, "unit": "lattice-arcs/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
            "sample": f"{len(lats)} lattices ({dp} arcs) x {reps} passes, float64 log-semiring forward-backward, "
                      f"OpenMP over lattices, {dt:.1f} s"}
     # cpu_ref_dense: the reference's own algorithm

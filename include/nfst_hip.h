@@ -27,6 +27,9 @@
  *   nfst_emission_mask                 FSAGRUScorer.mask_out_invalid
  *                                      (scorers.py:1037-1054)
  *   nfst_beta_logits                   beta-logit gather (scorers.py:581-593)
+ *   nfst_proposal_step (+ _backward)   one step of Sampler.stateful_sample on the lattice
+ *                                      side (samplers.py:243-297; scorers.py:340-366, 630-690)
+ *   nfst_backward_neural               compute_beta with Wh != 0 (scorers.py:692-856)
  *   nfst_gather_label_scores           WFSTScorer (scorers.py:1671-1687)
  *   nfst_path_logprob (+ _backward)    StaticRNNScorer.evaluate_seq_with_temp
  *                                      gather (scorers.py:1564-1611) and its gradient
@@ -289,19 +292,61 @@ int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *
                      float *out, int32_t k, void *stream);
 
 /*
+ * Optional operands of nfst_proposal_step (zero-initialise; NULL pointers switch a part off).
+ *   value_state [N]: the state whose transition row the `values` gather reads.  The reference gathers
+ *     its beta "logits" from the state BEFORE the previous symbol was consumed (scorers.py:584-590 run
+ *     inside super().actual_left_to_right_score, the advance is line 679) while the masks use the state
+ *     after it: pass the previous step's `state` here to reproduce that (pinned by
+ *     tests/golden/sampler_beta.npz); NULL = gather from `state`.
+ *   accumulated [N] int64, vocab_use [N, V] float32 (in/out, zeroed by the caller before the first
+ *     step): the counters of scorers.py:654-661, updated with the previous symbol `inp` first; then
+ *       scores[:, insertion_mark] -= insert_penalty * (length - insert_threshold)
+ *           where accumulated > insert_threshold             (if insert_threshold > 0; 663-669)
+ *       scores -= vocab_use * length_penalty                  (if 0 < length_threshold < length; 671-677)
+ *     `length` is the step's metadata["length"] (1 at the first step).
+ */
+typedef struct nfst_step_extras {
+  const int64_t *value_state;
+  int64_t *accumulated;
+  float *vocab_use;
+  int32_t insertion_mark;
+  int32_t insert_threshold;
+  float insert_penalty;
+  int32_t length_threshold;
+  float length_penalty;
+  int32_t length;
+} nfst_step_extras;
+
+/*
  * Fused lattice side of one proposal-sampler step (Sampler.stateful_sample, samplers.py:243-297;
  * left_to_right_score, scorers.py:340-366; mask_out_invalid, 1037-1054 + 59-83; beta-logit gather,
- * 581-593; update_fsa_state, 683-690): for every walker n (lattice n / k)
- *   logits = (pad_masking(scores[n, :]) [+ values[next state]] + emission row + legality masks) / temperature
+ * 581-593; penalties, 654-677; update_fsa_state, 683-690): for every walker n (lattice n / k)
+ *   logits = (pad_masking(scores[n, :] [+ values[next state]] [- penalties]) + emission row + legality masks) / temperature
  *   symbol = forced[n], or the first mark (in id order) whose CDF exceeds uniforms[n]
  *   logq = logits[symbol] - logsumexp(logits), logz = that logsumexp (optional), next_state as nfst_step.
- * inp (the previous symbols) may be NULL: no bos / pad / eos legality masks then.  values is row-indexed
- * [total_rows] (e.g. beta in the domain the caller's scorer expects) or NULL.  vocab <= 4096.
+ * `state` is the state after the previous symbol `inp` was consumed.  inp may be NULL: no bos / pad /
+ * eos legality masks and no counters then.  values is row-indexed [total_rows] (e.g. beta in the domain
+ * the caller's scorer expects) or NULL.  extras may be NULL.  logits_out (optional, [N, V]) receives the
+ * masked, scaled logits: what nfst_proposal_step_backward needs.  vocab <= 4096 (<= 3400 with
+ * extras->value_state).
  */
 int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_t *inp, const float *scores,
                        const float *values, int32_t pad, int32_t bos, int32_t eos, int32_t has_to_end, float temperature,
-                       const float *uniforms, const int64_t *forced, int64_t *symbol, float *logq, float *logz,
-                       int64_t *next_state, int32_t k, void *stream);
+                       const float *uniforms, const int64_t *forced, const nfst_step_extras *extras, int64_t *symbol,
+                       float *logq, float *logz, int64_t *next_state, float *logits_out, int32_t k, void *stream);
+
+/*
+ * Backward of nfst_proposal_step: the reference's Categorical.log_prob is differentiable in the
+ * proposal's logits (samplers.py:256-273; tune_proposal, lightning.py:339-406).  From the logits the
+ * forward pass wrote: grad_scores [N, V] = (g_logq * (onehot(symbol) - softmax) + g_logz * softmax) /
+ * temperature for legal marks other than pad, 0 elsewhere (g_logq, g_logz [N]; either may be NULL).
+ * grad_values (optional, [total_rows], zeroed by the caller) accumulates the same numbers through the
+ * next-state gather out of value_state (float atomics: the summation order is not fixed).
+ */
+int nfst_proposal_step_backward(const nfst_batch *lat, const int64_t *value_state, const float *logits,
+                                const int64_t *symbol, const float *logz, const float *g_logq, const float *g_logz,
+                                int32_t pad, float temperature, float *grad_scores, float *grad_values, int32_t k,
+                                void *stream);
 
 /*
  * Neuralised beta: FSAGRUScorer.compute_beta_per_sample with Wh != 0

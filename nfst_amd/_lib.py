@@ -49,6 +49,12 @@ class Scores(C.Structure):
                 ("slot_ws_ready", C.c_int64)]
 
 
+class StepExtras(C.Structure):
+    _fields_ = [("value_state", C.c_void_p), ("accumulated", C.c_void_p), ("vocab_use", C.c_void_p),
+                ("insertion_mark", C.c_int32), ("insert_threshold", C.c_int32), ("insert_penalty", C.c_float),
+                ("length_threshold", C.c_int32), ("length_penalty", C.c_float), ("length", C.c_int32)]
+
+
 class PackOpts(C.Structure):
     _fields_ = [("n_threads", C.c_int32), ("slots_per_lane", C.c_int32), ("group_mode", C.c_int32),
                 ("reserved1", C.c_int32)]
@@ -80,7 +86,9 @@ def _load():
         "nfst_step": (C.c_int, [BP, vp, vp, vp, i32, vp]),
         "nfst_emission_mask": (C.c_int, [BP, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
         "nfst_beta_logits": (C.c_int, [BP, vp, vp, vp, i32, vp]),
-        "nfst_proposal_step": (C.c_int, [BP, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]),
+        "nfst_proposal_step": (C.c_int, [BP, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, C.POINTER(StepExtras), vp, vp,
+                                         vp, vp, vp, i32, vp]),
+        "nfst_proposal_step_backward": (C.c_int, [BP, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, i32, vp]),
         "nfst_neural_ws_floats": (i64, [BP, i32]),
         "nfst_backward_neural": (C.c_int, [BP, vp, vp, vp, i32, vp, vp, vp, vp]),
         "nfst_gather_label_scores": (C.c_int, [BP, SP, vp, vp]),

@@ -294,20 +294,42 @@ int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *
 
 int nfst_proposal_step(const nfst_batch *lat, const int64_t *state, const int64_t *inp, const float *scores,
                        const float *values, int32_t pad, int32_t bos, int32_t eos, int32_t has_to_end, float temperature,
-                       const float *uniforms, const int64_t *forced, int64_t *symbol, float *logq, float *logz,
-                       int64_t *next_state, int32_t k, void *stream) {
+                       const float *uniforms, const int64_t *forced, const nfst_step_extras *extras, int64_t *symbol,
+                       float *logq, float *logz, int64_t *next_state, float *logits_out, int32_t k, void *stream) {
   int rc = check_batch(lat);
   if (rc) return rc;
   if (!state || !scores || !symbol || !logq || !next_state || k <= 0 || !(temperature > 0.0f)) return NFST_ERR_ARG;
   if (!uniforms && !forced) return NFST_ERR_ARG;
   if (pad < 0 || pad >= lat->vocab) return NFST_ERR_ARG;
   if (lat->vocab > kStepMaxVocab) return NFST_ERR_LIMIT;
+  nfst_step_extras ex = {};
+  if (extras) {
+    ex = *extras;
+    if ((ex.accumulated || ex.vocab_use) && (ex.insertion_mark < 0 || ex.insertion_mark >= lat->vocab || ex.length < 1))
+      return NFST_ERR_ARG;
+  }
   const int64_t n = (int64_t)lat->n_lattices * k;
-  const int64_t lds = (int64_t)kStepWaves * 2 * lat->vocab * 4;
+  const int64_t lds = (int64_t)kStepWaves * ((values && ex.value_state) ? 3 : 2) * lat->vocab * 4;
   if ((rc = set_lds(k_proposal_step, lds))) return rc;
   hipLaunchKernelGGL(k_proposal_step, dim3((unsigned)((n + kStepWaves - 1) / kStepWaves)), dim3(64 * kStepWaves), (size_t)lds,
                      (hipStream_t)stream, *lat, state, inp, scores, values, (int)pad, (int)bos, (int)eos, (int)has_to_end,
-                     temperature, uniforms, forced, symbol, logq, logz, next_state, (int)k, n);
+                     temperature, uniforms, forced, ex, symbol, logq, logz, next_state, logits_out, (int)k, n);
+  return hip_status(hipGetLastError());
+}
+
+int nfst_proposal_step_backward(const nfst_batch *lat, const int64_t *value_state, const float *logits,
+                                const int64_t *symbol, const float *logz, const float *g_logq, const float *g_logz,
+                                int32_t pad, float temperature, float *grad_scores, float *grad_values, int32_t k,
+                                void *stream) {
+  int rc = check_batch(lat);
+  if (rc) return rc;
+  if (!logits || !symbol || !logz || !grad_scores || k <= 0 || !(temperature > 0.0f)) return NFST_ERR_ARG;
+  if (grad_values && !value_state) return NFST_ERR_ARG;
+  if (!g_logq && !g_logz) return NFST_ERR_ARG;
+  const int64_t n = (int64_t)lat->n_lattices * k;
+  hipLaunchKernelGGL(k_proposal_step_bwd, dim3((unsigned)((n + kStepWaves - 1) / kStepWaves)), dim3(64 * kStepWaves), 0,
+                     (hipStream_t)stream, *lat, value_state, logits, symbol, logz, g_logq, g_logz, (int)pad, temperature,
+                     grad_scores, grad_values, (int)k, n);
   return hip_status(hipGetLastError());
 }
 

@@ -944,32 +944,39 @@ __global__ void k_iwae(const float *log_p, const float *log_q, int B, int K, flo
 
 // ------------------------------------------------------------------ fused proposal step
 // Fused lattice side of one proposal-sampler step (Sampler.stateful_sample, samplers.py:243-297):
-// logits = (pad_masking(scores) [+ values of the next states] + emission row + legality masks)
-// / temperature -> logsumexp, inverse-CDF sample on a supplied uniform (or the forced symbol),
-// its log probability, next state.  One wave per walker; the walker's row of logits and next
-// states lives in LDS (V <= kStepMaxVocab).
+// logits = (pad_masking(scores [+ values of the next states] [- insertion / length penalties])
+// + emission row + legality masks) / temperature -> logsumexp, inverse-CDF sample on a supplied
+// uniform (or the forced symbol), its log probability, next state.  One wave per walker; the
+// walker's row of logits and next states lives in LDS (V <= kStepMaxVocab).
 constexpr int kStepMaxVocab = 4096, kStepWaves = 4;
 __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
     nfst_batch lat, const int64_t *state, const int64_t *inp, const float *scores, const float *values, int pad, int bos,
-    int eos, int has_to_end, float temperature, const float *uniforms, const int64_t *forced, int64_t *symbol,
-    float *logq, float *logz, int64_t *next_state, int K, int64_t n_walkers) {
+    int eos, int has_to_end, float temperature, const float *uniforms, const int64_t *forced, nfst_step_extras ex,
+    int64_t *symbol, float *logq, float *logz, int64_t *next_state, float *logits_out, int K, int64_t n_walkers) {
   extern __shared__ float2 lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n = (int64_t)blockIdx.x * kStepWaves + wave;
   if (n >= n_walkers) return;
   const int V = lat.vocab;
-  float *xs = (float *)lds + (size_t)wave * 2 * V;  // logits of the walker's row
-  int *nx = (int *)(xs + V);                          // next state per mark (-1: no arc)
+  const bool own_row = values && ex.value_state;  // the value gather reads another state's transition row
+  const int per_wave = (own_row ? 3 : 2) * V;
+  float *xs = (float *)lds + (size_t)wave * per_wave;  // logits of the walker's row
+  int *nx = (int *)(xs + V);                            // next state per mark (-1: no arc)
+  int *nv = own_row ? nx + V : nx;                      // next state per mark from the value state (0: no arc)
   const int b = (int)(n / K);
   const Meta m = load_meta(lat.meta, b);
+  const int32_t *rp = lat.row_ptr + m.row_off + b;
   const int64_t s = state[n];
   int r0 = 0, r1 = 0;
-  if (s >= 0 && s < m.n_rows) {
-    const int32_t *rp = lat.row_ptr + m.row_off + b;
-    r0 = rp[s]; r1 = rp[s + 1];
-  }
+  if (s >= 0 && s < m.n_rows) { r0 = rp[s]; r1 = rp[s + 1]; }
   // LDS accesses of one wave execute in order: no barrier between the phases
   for (int v = lane; v < V; v += 64) { xs[v] = kNegInf; nx[v] = -1; }
+  if (own_row) {
+    for (int v = lane; v < V; v += 64) nv[v] = 0;  // like the dense gather: no arc reads row 0
+    const int64_t vs = ex.value_state[n];
+    if (vs >= 0 && vs < m.n_rows)
+      for (int a = rp[vs] + lane; a < rp[vs + 1]; a += 64) nv[lat.arc_label[a]] = lat.arc_dst[a];
+  }
   for (int a = r0 + lane; a < r1; a += 64) {  // the state's arcs carry distinct marks
     const int l = lat.arc_label[a];
     xs[l] = lat.weighted ? lat.arc_w[a] : 0.0f;
@@ -978,6 +985,26 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
   const int64_t prev = inp ? inp[n] : -1;
   const bool ended = inp && (prev == eos || prev == pad);
   const float rt = 1.0f / temperature;
+  // insertion / length penalties (scorers.py:654-677): the counters are updated with the previous
+  // symbol first, then read
+  float ins_pen = 0.0f, use_prev = 0.0f;
+  bool len_pen = false;
+  const float *vu = ex.vocab_use ? ex.vocab_use + (size_t)n * V : nullptr;
+  if (inp && prev >= 0 && prev < V) {
+    // every lane reads the old counters (one address each), then lane 0 stores the new ones: the
+    // loop below never reads a location this wave has just written
+    if (ex.accumulated) {
+      const int64_t acc = ex.accumulated[n] + (prev == ex.insertion_mark ? 1 : 0);
+      if (lane == 0) ex.accumulated[n] = acc;
+      if (ex.insert_threshold > 0 && acc > ex.insert_threshold)
+        ins_pen = ex.insert_penalty * (float)(ex.length - ex.insert_threshold);
+    }
+    if (vu) {
+      use_prev = vu[prev] + 1.0f;
+      if (lane == 0) ex.vocab_use[(size_t)n * V + prev] = use_prev;
+      len_pen = 0 < ex.length_threshold && ex.length_threshold < ex.length;
+    }
+  }
   float mx = kNegInf;
   for (int v = lane; v < V; v += 64) {
     float x = xs[v];
@@ -986,8 +1013,13 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
       if (has_to_end && !ended && v != eos) x = kNegInf;
     }
     if (x > kNegInf) {
-      float sc = (v == pad) ? 0.0f : scores[(size_t)n * V + v];  // pad_masking (scorers.py:182-187)
-      if (values) sc += values[m.row_off + nx[v]];
+      float sc = 0.0f;  // pad_masking of the summed scores (scorers.py:182-187, 357)
+      if (v != pad) {
+        sc = scores[(size_t)n * V + v];
+        if (values) sc += values[m.row_off + (own_row ? nv[v] : nx[v])];
+        if (v == ex.insertion_mark) sc -= ins_pen;
+        if (len_pen) sc -= (v == (int)prev ? use_prev : vu[v]) * ex.length_penalty;
+      }
       x = (sc + x) * rt;
     }
     xs[v] = x;
@@ -999,6 +1031,8 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
     for (int v = lane; v < V; v += 64) sm += __expf(xs[v] - mx);
   sm = wave_sum(sm);
   const float lz = (mx > kNegInf) ? mx + logf(sm) : kNegInf;  // no legal mark: log z = -inf, symbol = pad, log q = -inf
+  if (logits_out)
+    for (int v = lane; v < V; v += 64) logits_out[(size_t)n * V + v] = xs[v];
   int sym = -1;
   if (!(mx > kNegInf)) {
     sym = -1;
@@ -1032,5 +1066,51 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
     logq[n] = ok ? xs[sym] - lz : kNegInf;
     if (logz) logz[n] = lz;
     next_state[n] = (ok && nx[sym] >= 0) ? nx[sym] : 0;  // like nfst_step: 0 where the table has no arc
+  }
+}
+
+// Backward of the fused step with respect to the proposal network's scores (and optionally the
+// gathered values): the reference's Categorical.log_prob is differentiable in the logits
+// (samplers.py:256-273).  logits = the masked, scaled row the forward pass wrote out;
+//   d logq / d scores[v] = (onehot(symbol)[v] - p[v]) / T,   d logz / d scores[v] = p[v] / T
+// for legal marks other than pad (pad_masking multiplies the pad column by zero), p = softmax(logits).
+// grad_values (optional, row-indexed, zeroed by the caller) receives the same numbers through the
+// next-state gather (float atomics).  One wave per walker.
+__global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step_bwd(
+    nfst_batch lat, const int64_t *vstate, const float *logits, const int64_t *symbol, const float *logz, const float *g_logq,
+    const float *g_logz, int pad, float temperature, float *grad_scores, float *grad_values, int K, int64_t n_walkers) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * kStepWaves + wave;
+  if (n >= n_walkers) return;
+  const int V = lat.vocab;
+  const float rt = 1.0f / temperature;
+  const float gq = g_logq ? g_logq[n] : 0.0f, gz = g_logz ? g_logz[n] : 0.0f;
+  const float lz = logz[n];
+  const int sym = (int)symbol[n];
+  const float *x = logits + (size_t)n * V;
+  auto grad_of = [&](int v) {
+    const float xv = x[v];
+    if (!(xv > kNegInf) || !(lz > kNegInf) || v == pad) return 0.0f;
+    const float p = __expf(xv - lz);
+    return rt * (gq * ((v == sym ? 1.0f : 0.0f) - p) + gz * p);
+  };
+  for (int v = lane; v < V; v += 64) grad_scores[(size_t)n * V + v] = grad_of(v);
+  if (grad_values) {
+    const int b = (int)(n / K);
+    const Meta m = load_meta(lat.meta, b);
+    const int32_t *rp = lat.row_ptr + m.row_off + b;
+    const int64_t s = vstate[n];
+    // marks with an arc out of the value state add to that arc's destination row; every other legal
+    // mark read row 0 in the forward pass
+    float to_row0 = 0.0f;
+    for (int v = lane; v < V; v += 64) to_row0 += grad_of(v);
+    if (s >= 0 && s < m.n_rows)
+      for (int a = rp[s] + lane; a < rp[s + 1]; a += 64) {
+        const float gv = grad_of(lat.arc_label[a]);
+        if (gv != 0.0f) atomicAdd(grad_values + m.row_off + lat.arc_dst[a], gv);
+        to_row0 -= gv;
+      }
+    to_row0 = wave_sum(to_row0);
+    if (lane == 0 && to_row0 != 0.0f) atomicAdd(grad_values + m.row_off, to_row0);
   }
 }

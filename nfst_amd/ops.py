@@ -290,16 +290,73 @@ class ProposalStep(NamedTuple):
     next_state: torch.Tensor  # [N] int64
 
 
+class StepPenalties:
+    """The per-walker counters and the constants of the insertion / length penalties of
+    ``FSAGRUScorer.actual_left_to_right_score`` (scorers.py:654-677; defaults as its constructor, 930-933).
+    ``accumulated`` [N] and ``vocab_use`` [N, V] are updated in place by every ``proposal_step``."""
+
+    def __init__(self, n_walkers: int, vocab: int, device, insertion_mark: int, insert_threshold: int = 2,
+                 insert_penalty: float = 1000.0, length_threshold: int = 0, length_penalty: float = 1000.0):
+        self.accumulated = torch.zeros(n_walkers, dtype=torch.int64, device=device)
+        self.vocab_use = torch.zeros(n_walkers, vocab, dtype=torch.float32, device=device)
+        self.insertion_mark, self.insert_threshold, self.insert_penalty = int(insertion_mark), int(insert_threshold), float(insert_penalty)
+        self.length_threshold, self.length_penalty = int(length_threshold), float(length_penalty)
+
+
+class _ProposalStep(torch.autograd.Function):
+    """(logq, logz) differentiable in ``scores`` (and ``values``): d logq / d scores = (onehot(symbol) -
+    softmax(masked logits)) / T, as the reference's ``Categorical.log_prob`` (samplers.py:256-273)."""
+
+    @staticmethod
+    def forward(ctx, lat, scores, values, cfg):
+        (state, inp, pad, bos, eos, has_to_end, temperature, uniforms, forced, extras, vstate, k) = cfg
+        N, dev = state.shape[0], lat.device
+        need = scores.requires_grad or (values is not None and values.requires_grad)
+        sym = torch.empty(N, dtype=torch.int64, device=dev)
+        nxt = torch.empty(N, dtype=torch.int64, device=dev)
+        logq = torch.empty(N, dtype=torch.float32, device=dev)
+        logz = torch.empty(N, dtype=torch.float32, device=dev)
+        logits = torch.empty(N, lat.vocab, dtype=torch.float32, device=dev) if need else None
+        check(lib.nfst_proposal_step(C.byref(lat.c_struct()), _ptr(state), _ptr(inp), _ptr(scores), _ptr(values), int(pad),
+                                     int(bos), int(eos), int(bool(has_to_end)), float(temperature), _ptr(uniforms), _ptr(forced),
+                                     None if extras is None else C.byref(extras), _ptr(sym), _ptr(logq), _ptr(logz), _ptr(nxt),
+                                     _ptr(logits), int(k), _stream()), "nfst_proposal_step")
+        ctx.lat, ctx.k, ctx.pad, ctx.temperature = lat, k, pad, temperature
+        ctx.need_values = values is not None and values.requires_grad
+        ctx.n_values = 0 if values is None else values.shape[0]
+        ctx.save_for_backward(logits, sym, logz, vstate)
+        ctx.mark_non_differentiable(sym, nxt)
+        return sym, logq, logz, nxt
+
+    @staticmethod
+    def backward(ctx, _gs, g_logq, g_logz, _gn):
+        logits, sym, logz, vstate = ctx.saved_tensors
+        lat = ctx.lat
+        g_logq = None if g_logq is None else g_logq.to(torch.float32).contiguous()
+        g_logz = None if g_logz is None else g_logz.to(torch.float32).contiguous()
+        grad = torch.empty_like(logits)
+        gv = torch.zeros(ctx.n_values, dtype=torch.float32, device=logits.device) if ctx.need_values else None
+        check(lib.nfst_proposal_step_backward(C.byref(lat.c_struct()), _ptr(vstate), _ptr(logits), _ptr(sym), _ptr(logz),
+                                              _ptr(g_logq), _ptr(g_logz), int(ctx.pad), float(ctx.temperature), _ptr(grad),
+                                              _ptr(gv), int(ctx.k), _stream()), "nfst_proposal_step_backward")
+        return None, grad, gv, None
+
+
 def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, k: int = 1,
                   inp: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None, pad: int = 0, bos: int = 1,
                   eos: int = 2, has_to_end: bool = False, temperature: float = 1.0,
-                  uniforms: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None) -> ProposalStep:
+                  uniforms: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None,
+                  value_state: Optional[torch.Tensor] = None, penalties: Optional[StepPenalties] = None,
+                  length: int = 1) -> ProposalStep:
     """One step of the reference's proposal sampler on the lattice side, fused
     (Sampler.stateful_sample, samplers.py:243-297: left_to_right_score + mask_out_invalid +
     Categorical sample / log_prob + update_fsa_state).  ``scores`` [N, V] are the proposal
     network's outputs for this step; ``values`` (row-indexed, e.g. beta) are added through the
-    next-state gather of scorers.py:581-593; ``uniforms`` [N] drive the inverse-CDF draw, or
-    ``forced`` [N] gives the symbols to evaluate."""
+    next-state gather of scorers.py:581-593 -- out of ``value_state`` if given (the reference reads the
+    row of the state before the previous symbol was consumed), else out of ``state``; ``penalties``
+    carries the insertion / length penalty counters (scorers.py:654-677) and ``length`` is the step's
+    metadata["length"]; ``uniforms`` [N] drive the inverse-CDF draw, or ``forced`` [N] gives the symbols
+    to evaluate.  ``logq`` and ``logz`` are differentiable in ``scores`` and ``values``."""
     _need_gpu(lat)
     state = _walkers(lat, state, k, "state")
     N = state.shape[0]
@@ -319,14 +376,24 @@ def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, 
         uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous().reshape(N)
     if forced is not None:
         forced = forced.to(device=dev, dtype=torch.int64).contiguous().reshape(N)
-    sym = torch.empty(N, dtype=torch.int64, device=dev)
-    nxt = torch.empty(N, dtype=torch.int64, device=dev)
-    logq = torch.empty(N, dtype=torch.float32, device=dev)
-    logz = torch.empty(N, dtype=torch.float32, device=dev)
-    check(lib.nfst_proposal_step(C.byref(lat.c_struct()), _ptr(state), _ptr(inp), _ptr(scores), _ptr(values), int(pad),
-                                 int(bos), int(eos), int(bool(has_to_end)), float(temperature), _ptr(uniforms), _ptr(forced),
-                                 _ptr(sym), _ptr(logq), _ptr(logz), _ptr(nxt), int(k), _stream()), "nfst_proposal_step")
-    return ProposalStep(sym, logq, logz, nxt)
+    extras = None
+    if value_state is not None or penalties is not None:
+        extras = _lib.StepExtras()
+        if value_state is not None:
+            value_state = _walkers(lat, value_state, k, "value_state")
+            extras.value_state = value_state.data_ptr()
+        if penalties is not None:
+            if inp is None:
+                raise ValueError("penalties need the previous symbols `inp`")
+            if penalties.accumulated.shape != (N,) or penalties.vocab_use.shape != (N, lat.vocab):
+                raise ValueError("penalty counters do not match the walkers")
+            extras.accumulated, extras.vocab_use = penalties.accumulated.data_ptr(), penalties.vocab_use.data_ptr()
+            extras.insertion_mark, extras.insert_threshold = penalties.insertion_mark, penalties.insert_threshold
+            extras.insert_penalty, extras.length_threshold = penalties.insert_penalty, penalties.length_threshold
+            extras.length_penalty, extras.length = penalties.length_penalty, int(length)
+    vstate = value_state if value_state is not None else state
+    cfg = (state, inp, pad, bos, eos, has_to_end, temperature, uniforms, forced, extras, vstate, k)
+    return ProposalStep(*_ProposalStep.apply(lat, scores, values, cfg))
 
 
 class NeuralBeta(NamedTuple):

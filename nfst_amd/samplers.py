@@ -89,12 +89,22 @@ class ProposalSampler(Sampler):
     stays outside: ``score_fn(hx, inp) -> (new_hx, logits [N, V])`` is the reference's recurrent
     cell + output layer (``left_to_right_score`` without its masks).  Everything on the lattice
     side of a step -- emission and bos/pad/eos legality masks, the optional next-state value
-    gather (``use_beta``, scorers.py:581-593), temperature, the categorical draw or the forced
-    symbol, its log probability and the state advance -- is one ``nfst_proposal_step`` launch."""
+    gather (``use_beta``, scorers.py:581-593), the insertion / length penalties (654-677), temperature,
+    the categorical draw or the forced symbol, its log probability and the state advance -- is one
+    ``nfst_proposal_step`` launch.  ``log_q`` is differentiable in the network's logits and in ``values``
+    (the reference's ``Categorical.log_prob``, samplers.py:256-273; tune_proposal, lightning.py:339-406).
 
-    def __init__(self, model: LatticeScorer, score_fn):
+    ``penalties``: ``dict(insertion_mark=..., insert_threshold=2, insert_penalty=1000.0, length_threshold=0,
+    length_penalty=1000.0)`` switches on the penalties of ``FSAGRUScorer`` (constructor defaults,
+    scorers.py:930-933); ``beta_from_previous_state=True`` (the reference's order) gathers ``values`` from
+    the transition row of the state before the previous symbol was consumed."""
+
+    def __init__(self, model: LatticeScorer, score_fn, penalties: Optional[Dict] = None,
+                 beta_from_previous_state: bool = True):
         super().__init__(model)
         self.score_fn = score_fn
+        self.penalties = penalties
+        self.beta_from_previous_state = beta_from_previous_state
 
     def stateful_sample(self, batch_size: int, to_evaluate: Optional[torch.Tensor] = None, hx=None,
                         temperature: float = 1.0, values: Optional[torch.Tensor] = None,
@@ -113,7 +123,11 @@ class ProposalSampler(Sampler):
             padded = torch.cat([to_evaluate.to(device=dev, dtype=torch.int64), pad_col], dim=1)  # samplers.py:208-218
         inp = torch.full((batch_size,), m.__bos__, dtype=torch.int64, device=dev)
         # the implicit bos is consumed first (scorers.py:230-231, metadata "state" after inp0 = bos)
-        state = ops.step(lat, torch.zeros(batch_size, dtype=torch.int64, device=dev), inp, k=m.k)
+        prev_state = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        state = ops.step(lat, prev_state, inp, k=m.k)
+        pen = None
+        if self.penalties is not None:
+            pen = ops.StepPenalties(batch_size, lat.vocab, dev, **self.penalties)
         log_q = torch.zeros(batch_size, dtype=torch.float32, device=dev)
         zs = torch.zeros(batch_size, dtype=torch.float32, device=dev)
         prefixes = []
@@ -125,11 +139,13 @@ class ProposalSampler(Sampler):
             r = ops.proposal_step(lat, state, logits, k=m.k, inp=inp, values=values, pad=m.__pad__, bos=m.__bos__,
                                   eos=m.__eos__, has_to_end=(timestep + 1) > m.max_length, temperature=temperature,
                                   uniforms=None if (evaluate_only or uniforms is None) else uniforms[timestep],
-                                  forced=padded[:, timestep] if evaluate_only else None)
+                                  forced=padded[:, timestep] if evaluate_only else None,
+                                  value_state=prev_state if (values is not None and self.beta_from_previous_state) else None,
+                                  penalties=pen, length=timestep + 1)
             log_q = log_q + r.logq
             zs = zs + r.logz
             prefixes.append(r.symbol)
-            state, inp = r.next_state, r.symbol
+            prev_state, state, inp = state, r.next_state, r.symbol
             if self.all_reached_eos(r.symbol):
                 hard_cut = False
                 break

@@ -390,18 +390,34 @@ def gpt2_logprob(logits: np.ndarray, x: np.ndarray, pad: int, g: Optional[np.nda
 def proposal_step(emission_k: np.ndarray, transition_k: np.ndarray, scores: np.ndarray, inp: np.ndarray,
                   state: np.ndarray, length: int, max_length: int, pad: int, bos: int, eos: int,
                   temperature: float = 1.0, beta: Optional[np.ndarray] = None, uniforms: Optional[np.ndarray] = None,
-                  forced: Optional[np.ndarray] = None) -> dict:
+                  forced: Optional[np.ndarray] = None, value_state: Optional[np.ndarray] = None,
+                  penalties: Optional[dict] = None) -> dict:
     """One step of Sampler.stateful_sample (samplers.py:243-297) on the lattice side:
     left_to_right_score (scorers.py:340-366: pad_masking(scores) + mask_out_invalid, identity
     activation; with beta the gathered beta "logits" of scorers.py:581-593 are added to the scores),
     / temperature, Categorical(logits) -> sample (inverse CDF over the marks in id order on
     ``uniforms``) or evaluate ``forced``, log_prob, logsumexp, update_fsa_state (scorers.py:683-690).
+    ``state`` is the state after the previous symbol ``inp`` was consumed (the masks' state);
+    ``value_state`` the state the beta gather reads its transition row from -- in the reference the
+    state *before* ``inp`` was consumed (scorers.py:584-590 run before the advance at 679); None = ``state``.
+    ``penalties``: dict(accumulated [N] int, vocab_use [N, V] float -- both updated in place with
+    ``inp`` as scorers.py:654-661 does --, insertion_mark, insert_threshold, insert_penalty,
+    length_threshold, length_penalty): the insertion and length penalties of scorers.py:663-677.
     float64 arithmetic; ``margin`` = distance of u from the nearest CDF boundary."""
     N, V = scores.shape
     x = scores.astype(np.float64).copy()
-    x[:, pad] = 0.0  # pad_masking: the pad column's score counts as 0 (scorers.py:182-187)
     if beta is not None:
-        x = x + beta_logits(transition_k, beta, state).astype(np.float64)
+        x = x + beta_logits(transition_k, beta, state if value_state is None else value_state).astype(np.float64)
+    if penalties is not None:
+        pn = penalties
+        pn["accumulated"] += (inp == pn["insertion_mark"])
+        pn["vocab_use"][np.arange(N), inp] += 1
+        if pn["insert_threshold"] > 0:
+            hit = pn["accumulated"] > pn["insert_threshold"]
+            x[hit, pn["insertion_mark"]] -= pn["insert_penalty"] * (length - pn["insert_threshold"])
+        if 0 < pn["length_threshold"] < length:
+            x = x - pn["vocab_use"].astype(np.float64) * pn["length_penalty"]
+    x[:, pad] = 0.0  # pad_masking of the summed scores: the pad column counts as 0 (scorers.py:182-187, 357)
     x = (x + mask_out_invalid(emission_k, inp, state, length, max_length, pad, bos, eos).astype(np.float64)) / temperature
     mx = x.max(axis=1, keepdims=True)
     with np.errstate(invalid="ignore", divide="ignore"):

@@ -20,6 +20,23 @@ scores = torch.randn(N, T, V, device=dev)
 marks = torch.randint(3, V, (N, T), device=dev); marks[:, -1] = 2
 t = timeit(lambda: ops.path_logprob(scores, marks, max_length=400))
 out["path_logprob"] = {"shape": [N, T, V], "ms": t * 1e3, "GB/s": N * T * V * 4 / t / 1e9}
+# its backward: the rows are recomputed, N x T x V float32 read + as many written
+for tag, kw in (("eval", dict()), ("smoothing", dict(smoothing=0.1))):
+    sg = scores.clone().requires_grad_(True)
+    val = ops.path_logprob(sg, marks, max_length=400, **kw)
+    gout = torch.randn(N, device=dev)
+    t = timeit(lambda: torch.autograd.grad(val, sg, gout, retain_graph=True), n=20, w=3)
+    out[f"path_logprob_backward_{tag}"] = {"shape": [N, T, V], "ms": t * 1e3, "GB/s_read_plus_written": 2 * N * T * V * 4 / t / 1e9}
+    del sg, val
+for V2 in (128, 256, 512, 1000):
+    s2 = torch.randn(1024, 128, V2, device=dev, requires_grad=True)
+    m2 = torch.randint(3, V2, (1024, 128), device=dev)
+    v2 = ops.path_logprob(s2, m2, max_length=400)
+    g2 = torch.randn(1024, device=dev)
+    t = timeit(lambda: torch.autograd.grad(v2, s2, g2, retain_graph=True), n=20, w=3)
+    out[f"path_logprob_backward_V{V2}"] = {"shape": [1024, 128, V2], "ms": t * 1e3, "GB/s_read_plus_written": 2 * 1024 * 128 * V2 * 4 / t / 1e9}
+    del s2, v2
+del scores
 lats = synth.bench_batch(256)
 lat = LatticeBatch.from_synth(lats, device=dev)
 theta = torch.from_numpy(synth.label_scores(1, 256)).to(dev)

@@ -34,6 +34,8 @@ What is pinned (reference file:line):
   gpt2.npz       GPT2Wrapper.forward (transformer.py:34-52) on supplied logits: value
                  and gradient.
   strip.npz      Sampler.stripping_pad (samplers.py:162-180) with pad = 0 and pad = 7.
+  sampler_beta.npz  Sampler.stateful_sample with FSAGRUScorer(use_beta=True): recorded prefix
+                 scores, beta, insertion / length penalties (scorers.py:577-601, 630-681).
 """
 import os
 import sys
@@ -446,6 +448,49 @@ def make_gpt2():
     save("gpt2.npz", **out)
 
 
+def make_sampler_beta():
+    """Sampler.stateful_sample with the learned proposal FSAGRUScorer(use_beta=True) (samplers.py:182-335,
+    scorers.py:577-601 + 630-681): per step the recurrent cell's prefix scores (recorded by a forward hook
+    on ``beta_scorer``; the network itself is out of scope), the beta values of compute_beta() that are
+    added through the next-state gather of scorers.py:584-590, the insertion penalty
+    (insert_threshold > 0, scorers.py:663-669) and the length penalty (0 < length_threshold < length,
+    671-677).  Outputs: the samples and their log q.  Pins the order of the steps: the beta gather
+    reads the transition row of the state *before* the previous symbol is consumed (584-590 run inside
+    super().actual_left_to_right_score, the state advance is 679), the masks use the state after it."""
+    V = 24
+    lats = [
+        synth.layered_lattice(31, n_states=20, avg_degree=3.0, vocab=V, width=3, span=2),
+        synth.edit_lattice([10, 11, 12], [13, 14], vocab=V, seed=4),  # uses the marks 3, 4, 5 (insertion-mark = 5)
+    ]
+    em, tr = synth.collate_dense([l.dense() for l in lats], pad=PAD)
+    B, K = len(lats), 6
+    out = {"emission": em, "transition": tr, "K": np.int64(K)}
+    for tag, kw, temperature in (("a", dict(insert_threshold=1, insert_penalty=0.7, length_threshold=3, length_penalty=0.05), 1.0),
+                                 ("b", dict(insert_threshold=2, insert_penalty=1000.0, length_threshold=0, length_penalty=1000.0), 0.8)):
+        torch.manual_seed(7)
+        sc = FSAGRUScorer(hid_dim=8, vocab_size=V, pad=PAD, bos=BOS, eos=EOS, use_beta=True, max_length=48, **kw)
+        sc.eval()
+        with torch.no_grad():
+            sc.Wh.mul_(0.5)
+            sc.W.mul_(0.3)  # keeps beta (probability domain, added raw to the logits) of order one
+        rec = []
+        hook = sc.beta_scorer.register_forward_hook(lambda m, i, o: rec.append(o.detach().clone().numpy()))
+        sampler = Sampler(sc)
+        sampler.set_masks(transition=torch.from_numpy(tr), emission=torch.from_numpy(em))
+        sampler.set_k(K)
+        torch.manual_seed(99)
+        with torch.no_grad():
+            beta = sc.compute_beta().numpy().astype(np.float32)
+            log_q, samples, _ = sampler.stateful_sample(B * K, temperature=temperature)
+        hook.remove()
+        assert len(rec) == samples.shape[1] + 1
+        out.update({f"{tag}_beta": beta, f"{tag}_prefix_scores": np.stack(rec, 0).astype(np.float32),
+                    f"{tag}_samples": samples.numpy(), f"{tag}_log_q": log_q.numpy().astype(np.float32),
+                    f"{tag}_cfg": np.array([kw["insert_threshold"], kw["insert_penalty"], kw["length_threshold"],
+                                            kw["length_penalty"], temperature, 48, Vocab.lookup("insertion-mark")], np.float64)})
+    save("sampler_beta.npz", **out)
+
+
 def make_strip():
     """Sampler.stripping_pad (samplers.py:162-180) with pad != 0: marks equal to 0 are dropped, pad marks
     are kept, and a row that ends in a dropped 0 keeps one 0 after its last mark."""
@@ -467,6 +512,6 @@ def make_strip():
 if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py make_beta_neural`; nothing = all
     for fn in (make_beta, make_beta_neural, make_gather, make_sampler_and_iwae, make_evalseq, make_evalseq_grad, make_gpt2,
-               make_strip):
+               make_strip, make_sampler_beta):
         if not only or fn.__name__ in only:
             fn()

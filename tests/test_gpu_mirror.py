@@ -11,6 +11,7 @@ from oracle import oracle as O
 from nfst_amd import io, synth
 from nfst_amd.estimators import Estimators
 from nfst_amd.joint import JointProb
+from nfst_amd.lattice import LatticeBatch
 from nfst_amd.samplers import Sampler
 from nfst_amd.scorers import LatticeScorer
 
@@ -198,6 +199,109 @@ def test_proposal_sampler_replays_reference_sampler(dev, golden_dir):
             state = int(dst[legal][0])
         assert state == d["transition"].shape[1] - 1 or not ((src == state) & (dst != state)).any()
         assert abs(q_np[n] - ref) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_proposal_sampler_replays_reference_use_beta_sampler(dev, golden_dir, tag):
+    """The reference's learned proposal FSAGRUScorer(use_beta=True) under Sampler.stateful_sample
+    (fixture sampler_beta.npz: recorded per-step prefix scores of the recurrent cell, beta of
+    compute_beta(), insertion and length penalties, temperature): ProposalSampler, forced along the
+    reference's samples, returns the reference's log q -- with the beta gather out of the state before
+    the previous symbol was consumed, as the reference does (scorers.py:584-590 vs 679)."""
+    from nfst_amd.samplers import ProposalSampler
+    d = load(golden_dir, "sampler_beta")
+    K = int(d["K"])
+    ins_thr, ins_pen, len_thr, len_pen, temperature, max_length, ins_mark = d[f"{tag}_cfg"]
+    B, R, V = d["emission"].shape
+    N = B * K
+    sc = LatticeScorer(V, pad=PAD, bos=BOS, eos=EOS, max_length=int(max_length)).to(dev)
+    pre = torch.from_numpy(d[f"{tag}_prefix_scores"]).to(dev)
+    step = {"t": 0}
+
+    def score_fn(hx, inp):
+        t = step["t"]
+        step["t"] += 1
+        return hx, pre[t]
+
+    pen = dict(insertion_mark=int(ins_mark), insert_threshold=int(ins_thr), insert_penalty=float(ins_pen),
+               length_threshold=int(len_thr), length_penalty=float(len_pen))
+    sp = ProposalSampler(sc, score_fn, penalties=pen)
+    sp.set_masks(transition=torch.from_numpy(d["transition"]), emission=torch.from_numpy(d["emission"]))
+    sp.set_k(K)
+    beta = torch.from_numpy(d[f"{tag}_beta"][::K]).to(dev).reshape(-1)  # [B * (S+1)] row-indexed, probability domain
+    log_q, hx = sp.stateful_sample(N, to_evaluate=torch.from_numpy(d[f"{tag}_samples"]), values=beta,
+                                   temperature=float(temperature))
+    assert np.max(np.abs(log_q.cpu().numpy() - d[f"{tag}_log_q"])) < 1e-5
+    # the other order (beta gathered from the advanced state) does not reproduce the reference
+    step["t"] = 0
+    sp2 = ProposalSampler(sc, score_fn, penalties=pen, beta_from_previous_state=False)
+    log_q2, _ = sp2.stateful_sample(N, to_evaluate=torch.from_numpy(d[f"{tag}_samples"]), values=beta,
+                                    temperature=float(temperature))
+    assert np.max(np.abs(log_q2.cpu().numpy() - d[f"{tag}_log_q"])) > 1e-3
+    # sampling freely with the penalties on: every sample ends, log q is finite
+    step["t"] = 0
+    u = torch.rand(int(max_length) + 1, N, generator=torch.Generator().manual_seed(5))
+    pre_long = torch.zeros(int(max_length) + 1, N, V, device=dev)
+    pre_long[: pre.shape[0]] = pre
+
+    def score_long(hx, inp):
+        t = step["t"]
+        step["t"] += 1
+        return hx, pre_long[t]
+
+    sp3 = ProposalSampler(sc, score_long, penalties=pen)
+    lq3, samples3, _ = sp3.stateful_sample(N, values=beta, temperature=float(temperature), uniforms=u)
+    assert torch.isfinite(lq3).all() and samples3.shape[0] == N
+
+
+def test_proposal_step_autograd(dev):
+    """log q and log z of the fused step are differentiable in the proposal's scores and in the
+    gathered values; checked against torch.autograd (float64, CPU) on the dense restatement of the
+    step: logits = ((scores + values[next state]) * padmask + masks) / T."""
+    from nfst_amd import ops
+    from oracle import oracle as O
+    V, K = 48, 6
+    lats = [synth.layered_lattice(700 + i, n_states=40 + 25 * i, avg_degree=5.0, vocab=V, width=4, span=3) for i in range(3)]
+    em, tr = synth.collate_dense([l.dense() for l in lats])
+    lat = LatticeBatch.from_dense(em, tr, device=dev)
+    R = em.shape[1]
+    N = len(lats) * K
+    rng = np.random.default_rng(9)
+    em_k, tr_k = O.expand_k(em, K), O.expand_k(tr, K)
+    vstate = np.zeros(N, np.int64); state = np.zeros(N, np.int64); inp = np.zeros(N, np.int64)
+    for n in range(N):
+        l = lats[n // K]
+        a = int(rng.integers(0, l.n_arcs - 1))
+        while l.src[a] == l.dst[a]:
+            a = int(rng.integers(0, l.n_arcs - 1))
+        vstate[n], inp[n], state[n] = l.src[a], l.label[a], l.dst[a]
+    scores = rng.normal(0, 1.2, size=(N, V)).astype(np.float32)
+    values = rng.normal(0, 0.6, size=lat.total_rows).astype(np.float32)
+    u = rng.random(N).astype(np.float32)
+    gq, gz = rng.normal(size=N).astype(np.float32), rng.normal(size=N).astype(np.float32)
+    for T, own in ((1.0, True), (0.7, False)):
+        sc = torch.from_numpy(scores).to(dev).requires_grad_(True)
+        vl = torch.from_numpy(values).to(dev).requires_grad_(True)
+        r = ops.proposal_step(lat, torch.from_numpy(state), sc, k=K, inp=torch.from_numpy(inp), values=vl, pad=PAD, bos=BOS,
+                              eos=EOS, temperature=T, uniforms=torch.from_numpy(u),
+                              value_state=torch.from_numpy(vstate) if own else None)
+        (r.logq * torch.from_numpy(gq).to(dev) + r.logz * torch.from_numpy(gz).to(dev)).sum().backward()
+        sym = r.symbol.cpu().numpy()
+        # dense restatement in torch (float64)
+        mask = torch.from_numpy(O.mask_out_invalid(em_k, inp, state, 2, 300, PAD, BOS, EOS).astype(np.float64))
+        idx = torch.from_numpy(tr_k[np.arange(N), vstate if own else state])  # [N, V] next state per mark
+        roff = torch.from_numpy(np.repeat(lat.row_off.astype(np.int64), K))[:, None]
+        tsc = torch.from_numpy(scores.astype(np.float64)).requires_grad_(True)
+        tvl = torch.from_numpy(values.astype(np.float64)).requires_grad_(True)
+        pz = torch.ones(V, dtype=torch.float64); pz[PAD] = 0
+        x = ((tsc + tvl[roff + idx]) * pz + mask) / T
+        lp = torch.log_softmax(x, dim=1)
+        lq = lp[torch.arange(N), torch.from_numpy(sym)]
+        lz = torch.logsumexp(x, dim=1)
+        (lq * torch.from_numpy(gq.astype(np.float64)) + lz * torch.from_numpy(gz.astype(np.float64))).sum().backward()
+        assert np.max(np.abs(r.logq.detach().cpu().numpy() - lq.detach().numpy())) <= 2e-5
+        assert np.max(np.abs(sc.grad.cpu().numpy() - tsc.grad.numpy())) <= 2e-5
+        assert np.max(np.abs(vl.grad.cpu().numpy() - tvl.grad.numpy())) <= 5e-5
 
 
 def test_device_prefetcher_overlaps_copies_and_changes_nothing(dev):

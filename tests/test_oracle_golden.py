@@ -142,6 +142,41 @@ def test_proposal_step_replays_reference_sampler(golden_dir):
         assert row[PAD] and row.sum() == 1
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_proposal_step_replays_reference_use_beta_sampler(golden_dir, tag):
+    """FSAGRUScorer(use_beta=True) under Sampler.stateful_sample: recorded prefix scores + beta gathered
+    from the state before the previous symbol was consumed + insertion / length penalties, forced along
+    the reference's own samples, give the reference's log q.  (Gathering beta from the advanced state
+    instead does NOT reproduce it: the order is pinned here.)"""
+    d = load(golden_dir, "sampler_beta")
+    K = int(d["K"])
+    ins_thr, ins_pen, len_thr, len_pen, temperature, max_length, ins_mark = d[f"{tag}_cfg"]
+    samples, log_q, beta, pre = d[f"{tag}_samples"], d[f"{tag}_log_q"], d[f"{tag}_beta"], d[f"{tag}_prefix_scores"]
+    B, _, V = d["emission"].shape
+    em_k, tr_k = O.expand_k(d["emission"], K), O.expand_k(d["transition"], K)
+    N = B * K
+    padded = np.concatenate([samples, np.full((N, 1), PAD, np.int64)], axis=1)
+
+    def run(pre_advance):
+        pen = dict(accumulated=np.zeros(N, np.int64), vocab_use=np.zeros((N, V), np.float32), insertion_mark=int(ins_mark),
+                   insert_threshold=int(ins_thr), insert_penalty=float(ins_pen), length_threshold=int(len_thr),
+                   length_penalty=float(len_pen))
+        prev = np.zeros(N, np.int64)                 # the state before bos is consumed
+        state = tr_k[np.arange(N), 0, BOS].copy()    # ... and after
+        inp = np.full(N, BOS, np.int64)
+        acc = np.zeros(N)
+        for t in range(padded.shape[1]):
+            r = O.proposal_step(em_k, tr_k, pre[t], inp, state, t + 1, int(max_length), PAD, BOS, EOS,
+                                temperature=float(temperature), beta=beta, forced=padded[:, t],
+                                value_state=prev if pre_advance else None, penalties=pen)
+            acc += r["logq"]
+            prev, state, inp = state, r["next_state"], padded[:, t]
+        return acc
+
+    assert np.max(np.abs(run(True) - log_q)) < 1e-5
+    assert np.max(np.abs(run(False) - log_q)) > 1e-3
+
+
 def test_iwae_and_wfst_score(golden_dir):
     d = load(golden_dir, "iwae")
     theta = d["theta"]
