@@ -11,7 +11,9 @@ import os
 import torch  # noqa: F401  -- first, so that torch's bundled HIP runtime is the one the process uses
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnfst_hip.so")
+# NFST_LIB: an experimental build of the same sources (python -m nfst_amd.build --variant TAG -D...),
+# for A/B measurements inside one GPU box call; the product library otherwise
+LIB_PATH = os.environ.get("NFST_LIB") or os.path.join(_HERE, "lib", "libnfst_hip.so")
 
 META_WORDS = 16
 (META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_TILES, META_BWD_OFF,

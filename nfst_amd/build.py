@@ -24,20 +24,26 @@ def is_stale() -> bool:
     return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + DEPS + [HDR])
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+    """``variant`` + ``defines`` (-D flags): an experimental build of the same sources into
+    lib/variants/libnfst_hip_<variant>.so, loaded instead of the product library when the environment
+    names it in NFST_LIB (profiles/tune/*.sh: A/B runs inside one GPU box call)."""
+    out = OUT if not variant else os.path.join(HERE, "lib", "variants", f"libnfst_hip_{variant}.so")
+    if not variant and not force and not is_stale():
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-std=c++17",
-           "-I" + os.path.join(ROOT, "include"), "-Wall", "-Wextra", "-Wno-inline-asm", *SRC, "-o", OUT + ".tmp"]
+           "-I" + os.path.join(ROOT, "include"), "-Wall", "-Wextra", "-Wno-inline-asm", *defines, *SRC, "-o", out + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, variant=variant,
+                defines=[a for a in sys.argv[1:] if a.startswith("-D")]))
