@@ -28,10 +28,10 @@ struct LdsPlan {
     return (int64_t)R * kSlotWords + (int64_t)RS * (extra ? kRawWordsX : kRawWords);
   }
   __host__ __device__ int64_t fb_bytes(int R, int RS, bool extra) const {
-    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * sweep_words(R, RS, extra) * 4 + 32 + 1024;  // + 8 flag words + 64 x 8 bytes of trash per sweep
+    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * sweep_words(R, RS, extra) * 4 + 32;
   }
   __host__ __device__ int64_t bwd_bytes(int R, int RS, bool extra) const {
-    return ((int64_t)rows2 + v2) * 8 + sweep_words(R, RS, extra) * 4 + 16 + 512;  // + 4 flag words + 64 x 8 bytes of trash
+    return ((int64_t)rows2 + v2) * 8 + sweep_words(R, RS, extra) * 4 + 16;
   }
 };
 
@@ -48,8 +48,6 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int burst = max(RS >> 8, 1);  // the launcher packs the loader's burst length into RS
-  RS &= 0xff;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *beta = lds;
@@ -64,35 +62,23 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   const int32_t *bwd_extras = (const int32_t *)(sc.slot_ws + lat.fwd_slots + m.bwd_slot_off);
   constexpr bool kSelf = NT != 512;
   constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
-  const uint32_t *bprog = lat.bwd_stream + m.bwd_off;
-  int *flags = (int *)(ring + LdsPlan::sweep_words(R, RS, EXTRA));
-  auto init_phase = [&]() {
-    for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
-    load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
-    __syncthreads();
-    if (tid == 0) {
-      beta[m.sink] = make_float2(0.5f, __int_as_float(1));
-      flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
-    }
-    __syncthreads();
-  };
-  if (!kSelf && wv == 2) {  // the loader wave of the deep flavour: format dispatched outside (see k_forward_backward)
-    auto load_all = [&](auto &ld) {
-      ld.start(bprog, bwd_extras, m.bwd_tiles, lane);
-      init_phase();
-      ld.run(bprog, bwd_extras, m.bwd_tiles, raw, RS, flags + 1, flags + 2, lane);
-    };
-    if (m.bwd_u == 8) { TileLoader<8, EXTRA> ld; load_all(ld); }
-    else if (m.bwd_u == 4) { TileLoader<4, EXTRA> ld; load_all(ld); }
-    else if (m.bwd_u == 2) { TileLoader<2, EXTRA> ld; load_all(ld); }
-    else { TileLoader<1, EXTRA> ld; load_all(ld); }
-  } else {
-    if (kSelf && wv == 1) self_start<EXTRA, kAhead>(m.bwd_u, bprog, bwd_extras, m.bwd_tiles, raw, lane);
-    init_phase();
-    if (wv < 2)
-      run_sweep<EXTRA, kSelf, kAhead>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, bprog, bwd_extras,
-                m.bwd_tiles, ring, R, flags, beta, th, ex, lds_addr(flags + 4) + lane * 8, lane, burst);
+  if (kSelf) {
+    if (wv == 1) self_start<EXTRA, kAhead>(m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_extras, m.bwd_tiles, raw, lane);
+  } else if (wv == 2) {
+    loader_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_extras, m.bwd_tiles, raw, RS, lane);
   }
+  for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
+  __syncthreads();
+  int *flags = (int *)(ring + LdsPlan::sweep_words(R, RS, EXTRA));
+  if (tid == 0) {
+    beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
+  }
+  __syncthreads();
+  if (wv < (kSelf ? 2 : 3))
+    run_sweep<EXTRA, kSelf, kAhead>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off, bwd_extras,
+              m.bwd_tiles, ring, R, flags, beta, th, ex, lane);
   __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -104,15 +90,6 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
     if (beta_me) beta_me[m.row_off + i] = beta[i];
   }
 }
-
-#ifdef NFST_PROF  // (instrumented builds only: per-workgroup time stamps, 100 MHz)
-__device__ unsigned long long g_prof[4096 * 8];
-#define NFST_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_prof[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define NFST_STAMP_W(w, slot) do { if (threadIdx.x == (w) * 64 && blockIdx.x < 4096) g_prof[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define NFST_STAMP(slot)
-#define NFST_STAMP_W(w, slot)
-#endif
 
 // ------------------------------------------------------------------ forward-backward
 __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv, const float2 tw, float rz,
@@ -132,7 +109,7 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
 // synchronisation between them, fed by waves 2 and 3; after the one barrier that
 // follows every wave of the block streams canonical arcs for the posteriors.
-template <int NT, bool EXTRA, bool DIRECT = false>
+template <int NT, bool EXTRA>
 __global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, int R, int RS, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, double *__restrict__ logz_total, int total_slot,
@@ -140,9 +117,6 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  NFST_STAMP(0);
-  const int burst = max(RS >> 8, 1);  // the launcher packs the loader's burst length into RS
-  RS &= 0xff;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *alpha = lds;
@@ -169,93 +143,54 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // staging ring); otherwise two workgroups share a CU and the decoders load for themselves
   constexpr bool kSelf = NT != 1024;
   constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
-  static_assert(!DIRECT || kSelf, "the direct flavour loads for itself");
+  if (kSelf) {
+    if (wv == 2 || wv == 3) self_start<EXTRA, kAhead>(my_u, my_prog, my_perm, my_tiles, my_raw, lane);
+  } else if (wv == 6 || wv == 7) {
+    loader_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, my_raw, RS, lane);
+  }
+  for (int i = tid; i < m.n_rows; i += NT) {
+    alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
+    beta[i] = make_float2(0.0f, __int_as_float(kEZero));
+  }
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
+  if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
+  __syncthreads();
   int *flags = (int *)(ring + 2 * LdsPlan::sweep_words(R, RS, EXTRA));
+  if (tid == 0) {
+    beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+    alpha[0] = make_float2(0.5f, __int_as_float(1));
+    for (int i = 0; i < 8; ++i) flags[i] = 0;
+  }
+  __syncthreads();
   const bool want_post = posterior != nullptr || grad_theta != nullptr;
   const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
   // the posterior pass works on groups of 4 arcs (16-byte loads / stores) over the
   // aligned interior [v_begin, v_end) of the lattice's canonical arc range
   const int v_begin = (a_begin + 3) & ~3, v_end = a_end & ~3;
+  // The waves beyond the first four have nothing to do during the sweeps: they fetch
+  // their first kPre arc groups into registers now, so that after the sweeps the
+  // posterior pass starts on data that is already there.
   constexpr int kSweepThreads = 256;
   constexpr int kHelpers = NT - kSweepThreads;
   constexpr int kPre = (kHelpers > 0) ? 7 : 0;  // 7 x 768 x 4 = 21.5k arcs: a whole BASELINE lattice
   // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
   uint4 psd[kPre > 0 ? kPre : 1];
   uint2 plb[kPre > 0 ? kPre : 1];
-  // the workgroup's initialisation (every wave) ...
-  auto init_phase = [&]() {
-    for (int i = tid; i < m.n_rows; i += NT) {
-      alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
-      beta[i] = make_float2(0.0f, __int_as_float(kEZero));
-    }
-    load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
-    if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
-    __syncthreads();
-    if (tid == 0) {
-      beta[m.sink] = make_float2(0.5f, __int_as_float(1));
-      alpha[0] = make_float2(0.5f, __int_as_float(1));
-      for (int i = 0; i < 8; ++i) flags[i] = 0;
-    }
-    __syncthreads();
-    NFST_STAMP(1);
-    // ... and the waves beyond the first four, which have nothing else to do during the sweeps (or,
-    // the loader waves, little enough), fetch their first kPre arc groups into registers now, so that
-    // after the sweeps the posterior pass starts on data that is already there.
-    if (kPre > 0 && tid >= kSweepThreads && want_post) {
+  if (kPre > 0 && tid >= kSweepThreads && want_post) {
 #pragma unroll
-      for (int u = 0; u < kPre; ++u) {
-        const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
-        if (a < v_end) {
-          psd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
-          plb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
-        }
+    for (int u = 0; u < kPre; ++u) {
+      const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
+      if (a < v_end) {
+        psd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
+        plb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
       }
     }
-  };
-  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 6 / 7 load for them
-  if (!kSelf && (wv == 6 || wv == 7)) {
-    // a loader wave of the deep flavour: the program format is dispatched here, outside, so that one
-    // TileLoader object (kLoadDepth register sets) is alive on a path, from its first loads at kernel
-    // entry across the initialisation to the end of its loop
-    int *fl = bwd_side ? flags : flags + 4;
-    auto load_all = [&](auto &ld) {
-      ld.start(my_prog, my_perm, my_tiles, lane);
-      init_phase();
-      ld.run(my_prog, my_perm, my_tiles, my_raw, RS, fl + 1, fl + 2, lane);
-    };
-    if (my_u == 8) { TileLoader<8, EXTRA> ld; load_all(ld); }
-    else if (my_u == 4) { TileLoader<4, EXTRA> ld; load_all(ld); }
-    else if (my_u == 2) { TileLoader<2, EXTRA> ld; load_all(ld); }
-    else { TileLoader<1, EXTRA> ld; load_all(ld); }
-  } else {
-    if (DIRECT) {  // the sweep waves load, decode and sweep (tile_sweep_direct)
-      if (wv < 2) self_start<EXTRA, kAhead>(my_u, my_prog, my_perm, my_tiles, my_raw, lane);
-    } else if (kSelf) {
-      if (wv == 2 || wv == 3) self_start<EXTRA, kAhead>(my_u, my_prog, my_perm, my_tiles, my_raw, lane);
-    }
-    init_phase();
-#ifdef NFST_ABL_NOSWEEP  // (ablation builds only: everything but the sweeps)
-    if constexpr (false) {
-#else
-    if constexpr (DIRECT) {
-#endif
-      if (wv < 2) run_sweep_direct<EXTRA, kAhead>(my_u, my_wide, my_raw, my_prog, my_perm, my_tiles, bwd_side ? beta : alpha, th,
-                                                 lds_addr(flags + 8) + (bwd_side ? 0 : 512) + lane * 8, lane);
-    } else if (
-#ifdef NFST_ABL_NOSWEEP
-        false &&
-#endif
-        wv < 4)
-      run_sweep<EXTRA, kSelf, kAhead>(wv >> 1, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
-                       bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex,
-                       lds_addr(flags + 8) + (bwd_side ? 0 : 512) + lane * 8, lane, burst);
   }
-  NFST_STAMP_W(0, 2);  // beta sweep done
-  NFST_STAMP_W(1, 3);  // alpha sweep done
-  NFST_STAMP_W(2, 5);  // beta decoder done
-  NFST_STAMP_W(6, 6);  // beta loader done
+  // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 6 / 7 load for them
+  if (wv < 4 || (!kSelf && (wv == 6 || wv == 7)))
+    run_sweep<EXTRA, kSelf, kAhead>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
+                     bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex, lane);
   __syncthreads();
-  NFST_STAMP(4);
   const float2 zme = beta[0];
   if (tid == 0) {
     const double z = me_log64(zme);
@@ -333,8 +268,4 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       for (int l = tid; l < lat.vocab; l += NT) gout[l] = gth[l];
     }
   }
-#ifdef NFST_PROF
-  __syncthreads();
-  if (tid == 0) { g_prof[b * 8 + 7] = __builtin_amdgcn_s_memrealtime(); }
-#endif
 }

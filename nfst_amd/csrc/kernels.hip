@@ -123,18 +123,6 @@ static int64_t lds_reserve() {
   return v;
 }
 
-// experiment knobs (environment, read once): NFST_TUNE_RS = staging slots of the deep flavour,
-// NFST_TUNE_BURST = tiles the loader issues back to back
-static int tune(const char *name, int dflt, int lo, int hi) {
-  const char *e = getenv(name);
-  if (!e) return dflt;
-  const long v = strtol(e, nullptr, 10);
-  return (v >= lo && v <= hi) ? (int)v : dflt;
-}
-static int raw_slots_deep() { static int v = tune("NFST_TUNE_RS", kRawSlotsDeep, kDmaAheadDeep + 1, 40); return v; }
-static int loader_burst() { static int v = tune("NFST_TUNE_BURST", 1, 1, 8); return v; }
-static int use_direct() { static int v = tune("NFST_TUNE_DIRECT", 0, 0, 1); return v; }
-
 struct RingCfg { int R, RS; bool self; };
 static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, RingCfg *c) {
   const int n_rings = fb ? 2 : 1;
@@ -142,8 +130,8 @@ static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, Rin
   auto fixed = [&](int RS) { return fb ? plan.fb_bytes(0, RS, extra) : plan.bwd_bytes(0, RS, extra); };
   auto clampr = [](int64_t r) { return (int)(r > kMaxRing ? kMaxRing : r); };
   if (deep) {
-    const int64_t r = (kMaxLds - lds_reserve() - fixed(raw_slots_deep())) / slot;
-    if (r >= kMinRing) { *c = {clampr(r), raw_slots_deep(), false}; return true; }
+    const int64_t r = (kMaxLds - lds_reserve() - fixed(kRawSlotsDeep)) / slot;
+    if (r >= kMinRing) { *c = {clampr(r), kRawSlotsDeep, false}; return true; }
   } else {
     const int64_t r = (kMaxLds / 2 - fixed(kRawSlotsShared)) / slot;
     if (r >= kMinRing + 1) { *c = {clampr(r), kRawSlotsShared, true}; return true; }
@@ -169,9 +157,8 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
       hipLaunchKernelGGL(k_slot_extras, dim3((unsigned)((lat->bwd_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *lat,
                          *scores, (int64_t)lat->fwd_slots, (int64_t)(lat->fwd_slots + lat->bwd_slots));
   }
-  const int R = cfg.R;
-  const int64_t lds = plan.bwd_bytes(R, cfg.RS, extra);
-  const int RS = cfg.RS | (loader_burst() << 8);
+  const int R = cfg.R, RS = cfg.RS;
+  const int64_t lds = plan.bwd_bytes(R, RS, extra);
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
   {                                                                                                    \
     if ((rc = set_lds(k_backward<NT, EX>, lds))) return rc;                                            \
@@ -199,9 +186,6 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   const int cus = cu_count();
   RingCfg cfg;
   if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
-  // more lattices than CUs: the sweep waves decode for themselves (no decoded rings: R = 0)
-  const bool direct = use_direct() && cfg.self;
-  if (direct) cfg = {0, kRawSlotsShared, true};
   if (extra) {  // slot-ordered extras of both programs
     if (!scores->slot_ws) return NFST_ERR_ARG;
     const int64_t n = lat->fwd_slots + lat->bwd_slots;
@@ -209,9 +193,8 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
       hipLaunchKernelGGL(k_slot_extras, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *lat, *scores,
                          (int64_t)0, n);
   }
-  const int R = cfg.R;
-  const int64_t lds = plan.fb_bytes(R, cfg.RS, extra);
-  const int RS = cfg.RS | (loader_burst() << 8);
+  const int R = cfg.R, RS = cfg.RS;
+  const int64_t lds = plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
     if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
@@ -222,27 +205,12 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   }
   // 1024 threads: loaders + decoders + sweeps and 10 more waves for the posterior pass (deep);
   // 512 / 256 threads: self-loading decoders + sweeps, two workgroups per CU when they fit
-#define NFST_LAUNCH_FBD(EX)                                                                               \
-  {                                                                                                     \
-    if ((rc = set_lds(k_forward_backward<256, EX, true>, lds))) return rc;                              \
-    hipLaunchKernelGGL((k_forward_backward<256, EX, true>), dim3(lat->n_lattices), dim3(256), (size_t)lds, \
-                       (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, logz_total,    \
-                       (int)total_slot, posterior, grad_theta, (float2 *)beta_me);                      \
-  }
-  if (direct) { if (extra) NFST_LAUNCH_FBD(true) else NFST_LAUNCH_FBD(false) }
-  else if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
+  if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
   else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
   else { if (extra) NFST_LAUNCH_FB(256, true) else NFST_LAUNCH_FB(256, false) }
 #undef NFST_LAUNCH_FB
-#undef NFST_LAUNCH_FBD
   return hip_status(hipGetLastError());
 }
-
-#ifdef NFST_PROF
-int nfst_prof_read(unsigned long long *out, int n_words) {
-  return hip_status(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * (size_t)n_words));
-}
-#endif
 
 int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, int32_t *paths,
                  int32_t *path_arcs, int32_t *lengths, int32_t max_len, int32_t pad, void *stream) {

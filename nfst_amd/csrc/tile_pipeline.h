@@ -36,13 +36,7 @@
 //   then               (m, e) weights, slots (2k, 2k+1) of all lanes in block k (16 B per lane)
 // tiles the loader keeps in flight (HBM -> LDS by LDS-DMA) and raw-tile staging slots per
 // sweep: deep when a workgroup has a CU's LDS to itself, shallow when two share it
-#ifndef NFST_DEEP_AHEAD
-#define NFST_DEEP_AHEAD 8
-#endif
-#ifndef NFST_DEEP_RS
-#define NFST_DEEP_RS 12
-#endif
-constexpr int kDmaAheadDeep = NFST_DEEP_AHEAD, kRawSlotsDeep = NFST_DEEP_RS, kDmaAheadShared = 4, kRawSlotsShared = kDmaAheadShared + 1;
+constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = kDmaAheadShared + 1;
 constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
 constexpr int kRawWordsX = kRawWords + 64 * 4;  // + the slots' canonical arc ids (kernels with per-arc extras)
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
@@ -185,91 +179,6 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-// Fast reduce for groups of up to 8 lanes.  Scaling by a power of two is exact, so the group's terms
-// may be aligned to ANY common exponent that keeps them inside float32's range -- not only to their
-// maximum.  The reference is the exponent of lane 0's partial sum (one v_readfirstlane instead of a
-// three-stage masked max all-reduce); the sum over the state's lanes is three v_fmac_f32_dpp whose
-// multiplier K_s = (g > s) ? 1 : 0 switches a stage off for lanes whose state owns at most 2^s lanes
-// (partners always agree: groups are 2^g-aligned) -- no execution-mask changes.  A tile in which some
-// non-zero partial sum lies more than 2^64 away from the reference (`bad`) is redone by the exact
-// path by the caller; with sums that close the bits are those of the exact path.
-__device__ __forceinline__ float seg_sum_fmac3(float M, float gf) {
-  float k0, k1, k2;
-  asm volatile(
-      "v_max_f32_e64 %[k0], %[g], %[g] clamp\n\t"
-      "v_add_f32_e64 %[k1], %[g], -1.0 clamp\n\t"
-      "v_fmac_f32_dpp %[m], %[m], %[k0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_e64 %[k2], %[g], -2.0 clamp\n\t"
-      "s_nop 0\n\t"
-      "v_fmac_f32_dpp %[m], %[m], %[k1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_fmac_f32_dpp %[m], %[m], %[k2] row_half_mirror row_mask:0xf bank_mask:0xf"
-      : [m] "+v"(M), [k0] "=&v"(k0), [k1] "=&v"(k1), [k2] "=&v"(k2)
-      : [g] "v"(gf));
-  return M;
-}
-
-// One tile of a sum-product sweep: this lane's U products, their sum, the sum over the state's
-// lanes, normalisation, the leaders' stores.  `trash` is a per-lane LDS location the other lanes store
-// to (no execution-mask change, no branch).
-//
-// Fast path (groups of up to 8 lanes).  Scaling by a power of two is exact, so the terms of a state
-// may be aligned to ANY common exponent that keeps them inside float32's range, not only to their
-// maximum.  The reference `ref` is wave-uniform and one tile old (the exponent lane 0 ended the
-// previous tile with: values drift by a few binary orders per level), so it costs the dependency
-// chain nothing: a term is one multiply, one three-operand add and one ldexp; no maximum of
-// exponents, no rescale.  A tile in which some lane's largest non-zero term lies more than 2^64
-// away from the reference is redone by the exact path (maximum of exponents over the state's lanes
-// first); everywhere else the two paths give the same bits (terms more than 2^60 below a lane's
-// largest cannot change a float32 sum).  Exact zeros carry the exponent kEZero (about -2^28): a
-// lane whose terms are all zero is recognised by that and never forces the exact path.
-template <int U, bool WIDE>
-__device__ __forceinline__ void tile_math(const float (&mw)[U], const int (&ew)[U], const v2f (&vv)[U], uint32_t ctl,
-                                          uint32_t dst_addr, uint32_t trash, bool wide_tile, int &ref) {
-  const int gl = (int)((ctl >> 20) & 7u);
-  const bool leader = (int)ctl < 0;
-  const int nref = -ref;
-  float mt[U];
-  int d[U];
-#pragma unroll
-  for (int j = 0; j < U; ++j) {
-    mt[j] = mw[j] * vv[j].x;
-    d[j] = ew[j] + __float_as_int(vv[j].y) + nref;
-  }
-  int dmax = d[0];
-#pragma unroll
-  for (int j = 1; j < U; ++j) dmax = max(dmax, d[j]);
-  float M = ldexpf(mt[0], d[0]);
-#pragma unroll
-  for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j]);
-  constexpr int kZeroish = -(1 << 27);
-  const bool bad = ((uint32_t)(dmax + 64) > 128u) & (dmax > kZeroish);
-  int E = ref;
-  // the next tile's reference: where lane 0 stands now (kept if lane 0 holds nothing)
-  const int e0 = __builtin_amdgcn_readfirstlane(dmax);
-  const int ref_old = ref;
-  ref = (e0 > kZeroish) ? e0 + ref_old : ref_old;
-  if (__builtin_expect((WIDE && wide_tile) || __builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
-    // exact path: this lane's sum relative to its largest term, then the maximum over the state's lanes
-    M = ldexpf(mt[0], d[0] - dmax);
-#pragma unroll
-    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j] - dmax);
-    E = dmax + ref_old;
-    if (WIDE && wide_tile) {
-      seg_reduce_n<6>(M, E, gl);
-    } else {
-      const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
-                     m2 = __builtin_amdgcn_ballot_w64(gl > 2);
-      seg_reduce_exec<3>(M, E, m0, m1, m2);
-    }
-  } else {
-    M = seg_sum_fmac3(M, (float)gl);
-    E = (M == 0.0f) ? kEZero : E;  // an exact zero keeps the exponent that never wins a maximum
-  }
-  const float2 r = me_pack(M, E);
-  *(lds_v2f *)(uintptr_t)(leader ? dst_addr : trash) = v2f{r.x, r.y};  // trash: this lane's own 8 bytes (no bank conflict)
-}
-
 // ---- producer / consumer protocol -------------------------------------------------
 // Two LDS words per sweep, both only grow:
 //   land: tiles 0 .. land-1 are decoded and in the ring (written by the decoder)
@@ -284,14 +193,11 @@ __device__ __forceinline__ void tile_math(const float (&mw)[U], const int (&ew)[
 // register copy can touch it early.  Only full-wave 4- and 16-byte forms are used (the
 // 12-byte and exec-masked forms do not lay lanes out at lane x size on gfx950).  `nt`: a tile
 // program is read once per launch by one CU (measured: 1-2 % on the whole step).
-#ifndef NFST_DMA_POLICY
-#define NFST_DMA_POLICY " nt"
-#endif
 __device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" NFST_DMA_POLICY ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
 }
 __device__ __forceinline__ void lds_dma4(const void *gsrc, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" NFST_DMA_POLICY ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt" ::"s"(lds_dst), "v"(gsrc) : "m0", "memory");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait() {  // at most N vector-memory operations of this wave stay in flight
@@ -332,140 +238,78 @@ __device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *per
 }
 
 // ---- loader wave ------------------------------------------------------------------
-// Measured on gfx950 (profiles/ubench/read_patterns.hip, r02): two loader waves per CU stream the
-// tile programs of a whole BASELINE batch in 11 us (6.8 TB/s) with LDS-DMA -- but ONE LDS
-// instruction of the loading wave per tile (a flag store, or a flag load) beside the DMAs makes
-// that 57 us (1.3 TB/s): an LDS access of a wave waits for the LDS-DMAs that wave has in flight, so
-// a wave that also talks to its consumer through LDS runs with a queue of depth one.  The loader
-// therefore stages tiles through REGISTERS: plain global loads (the LDS pipe does not order
-// those), kLoadDepth tiles in flight in kLoadDepth register sets, then ds_write into the staging
-// ring and the flag store.  Loads are issued and waited for in inline asm with the destination
-// registers tied to the wait, so the compiler can neither drain the queue nor touch a register
-// set before its data has arrived.
-// flags (LDS words, all only grow): rland = raw tiles 0 .. rland-1 are in the staging ring; the
-// decoder's `land` (tiles decoded) tells which staging slots are free.
-constexpr int kLoadDepth = 8;
-template <int F, bool EXTRA>
-struct TileRegs {  // only the members a format uses ever hold data (the others cost no registers)
-  uint32_t c;      // control words (32-bit record formats)
-  v4u a;           // U = 4: records (compact: control word + records)
-  v2u a2;          // U = 2: records
-  uint32_t a1;     // U = 1: record
-  v4u x;           // slot-ordered extras, U = 4
-  v2u x2;
-  uint32_t x1;
-};
-__device__ __forceinline__ void gload4(v4u &d, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void gload2(v2u &d, const void *p) { asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void gload1(uint32_t &d, const void *p) { asm volatile("global_load_dword %0, %1, off nt" : "=v"(d) : "v"(p) : "memory"); }
-template <int F, bool EXTRA>
-__device__ __forceinline__ void tile_load(const uint32_t *g, const int32_t *perm, int tile, int lane, TileRegs<F, EXTRA> &r) {
-  constexpr int U = fmt_u(F);
-  const uint32_t *src = g + (size_t)tile * fmt_words(F);
-  const int32_t *q = perm + (size_t)tile * (64 * U);
-  if (F == 8) {
-    gload4(r.a, src + lane * 4);
-    if (EXTRA) gload4(r.x, q + lane * 4);
-    return;
-  }
-  gload1(r.c, src + lane);
-  if (U == 4) {
-    gload4(r.a, src + 64 + lane * 4);
-    if (EXTRA) gload4(r.x, q + lane * 4);
-  } else if (U == 2) {
-    gload2(r.a2, src + 64 + lane * 2);
-    if (EXTRA) gload2(r.x2, q + lane * 2);
-  } else {
-    gload1(r.a1, src + 64 + lane);
-    if (EXTRA) gload1(r.x1, q + lane);
-  }
-}
-// at most N loads of this wave stay in flight; the registers of `r` are tied to the wait: nothing
-// reads them before it
-template <int N, int F, bool EXTRA>
-__device__ __forceinline__ void tile_wait(TileRegs<F, EXTRA> &r) {
-  static_assert(N >= 0 && N <= 63, "vmcnt is 6 bits");
-  constexpr int U = fmt_u(F);
-  if (F == 8) {
-    if (EXTRA) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.a), "+v"(r.x) : "n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r.a) : "n"(N) : "memory");
-  } else if (U == 4) {
-    if (EXTRA) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.c), "+v"(r.a), "+v"(r.x) : "n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.c), "+v"(r.a) : "n"(N) : "memory");
-  } else if (U == 2) {
-    if (EXTRA) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.c), "+v"(r.a2), "+v"(r.x2) : "n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.c), "+v"(r.a2) : "n"(N) : "memory");
-  } else {
-    if (EXTRA) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.c), "+v"(r.a1), "+v"(r.x1) : "n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.c), "+v"(r.a1) : "n"(N) : "memory");
-  }
-}
-// registers -> the staging slot layout raw_fetch() reads
-template <int F, bool EXTRA>
-__device__ __forceinline__ void tile_stage(uint32_t slot_addr, int lane, const TileRegs<F, EXTRA> &r) {
-  constexpr int U = fmt_u(F);
-  if (F == 8) {
-    *(lds_v4u *)(uintptr_t)(slot_addr + lane * 16) = r.a;
-    if (EXTRA) *(lds_v4u *)(uintptr_t)(slot_addr + 1024 + lane * 16) = r.x;
-    return;
-  }
-  *(lds_u32 *)(uintptr_t)(slot_addr + lane * 4) = r.c;
-  if (U == 4) {
-    *(lds_v4u *)(uintptr_t)(slot_addr + 256 + lane * 16) = r.a;
-    if (EXTRA) *(lds_v4u *)(uintptr_t)(slot_addr + 256 + 1024 + lane * 16) = r.x;
-  } else if (U == 2) {
-    *(lds_v2u *)(uintptr_t)(slot_addr + 256 + lane * 8) = r.a2;
-    if (EXTRA) *(lds_v2u *)(uintptr_t)(slot_addr + 768 + lane * 8) = r.x2;
-  } else {
-    *(lds_u32 *)(uintptr_t)(slot_addr + 256 + lane * 4) = r.a1;
-    if (EXTRA) *(lds_u32 *)(uintptr_t)(slot_addr + 512 + lane * 4) = r.x1;
+// flags (LDS words, all only grow): rland = raw tiles 0 .. rland-1 have landed in the
+// staging ring; the decoder's `land` (tiles decoded) tells which staging slots are free.
+// part 1 (kernel entry, before anything else): the first ring-full needs no hand-shake,
+// so it is in flight while the workgroup initialises
+template <bool EXTRA>
+__device__ __forceinline__ void loader_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
+                                             int RS, int lane) {
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw);
+  const int n = min(n_tiles, RS);
+  for (int d = 0; d < n; ++d) {
+    if (U == 8) tile_issue<8, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else if (U == 4) tile_issue<4, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else if (U == 2) tile_issue<2, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    else tile_issue<1, EXTRA>(g, perm, d, raw_base + d * RB, lane);
   }
 }
 
-// The loader of one sweep: kernel entry issues the first kLoadDepth tiles (start), the loop runs
-// after the workgroup's initialisation.  One object per loader wave; its register sets live across
-// the barriers in between.
-template <int F, bool EXTRA>
-struct TileLoader {
-  static constexpr int K = kLoadDepth;
-  static constexpr int OPS = (F == 8 ? 1 : 2) + (EXTRA ? 1 : 0);  // loads tile_load() issues per tile
-  static_assert(OPS * K <= 63, "vmcnt is 6 bits");
-  TileRegs<F, EXTRA> r[K];
-  __device__ __forceinline__ void start(const uint32_t *g, const int32_t *perm, int n_tiles, int lane) {
-    const int last = max(n_tiles - 1, 0);
-#pragma unroll
-    for (int d = 0; d < K; ++d)  // short programs load their last tile again: the count stays constant
-      tile_load<F, EXTRA>(g, perm, min(d, last), lane, r[d]);
-  }
-  __device__ __forceinline__ void run(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int RS,
-                                      const int *land, int *rland, int lane) {
-    constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
-    const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
-    uint32_t rb = raw_base;  // staging slot of tile t
-    int freed = 0;           // copy of the decoder's counter
-    const int last = n_tiles - 1;
-    for (int t0 = 0; t0 < n_tiles; t0 += K) {
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const int t = t0 + j;
-        if (t < n_tiles) {  // wave-uniform
-          // the staging slot of tile t is free once the decoder has passed tile t - RS
-          while (__builtin_expect(t - freed >= RS, 0)) {
-            freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
-            if (t - freed >= RS) __builtin_amdgcn_s_sleep(1);
-          }
-          tile_wait<OPS * (K - 1)>(r[j]);
-          tile_stage<F, EXTRA>(rb, lane, r[j]);
-          asm volatile("" ::: "memory");
-          lds_flag_store(rland, t + 1);  // LDS accesses of one wave execute in order: the data precede the flag
-          rb = (rb + RB == raw_end) ? raw_base : rb + RB;
-          tile_load<F, EXTRA>(g, perm, min(t + K, last), lane, r[j]);  // past the end: the last tile again, never staged
-        }
+// blocks until at most `tiles` tiles (OPS LDS-DMA instructions each) are in flight;
+// vmcnt takes an immediate, hence the chain
+template <int OPS, int MAXT>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if (MAXT > 0 && tiles >= MAXT) vm_wait<(OPS * MAXT > 63 ? 63 : OPS * MAXT)>();
+  else if (MAXT > 0) wait_tiles_in_flight<OPS, (MAXT > 0 ? MAXT - 1 : 0)>(tiles);
+  else vm_wait<0>();
+}
+
+// part 2: streams the rest of the tile program into the staging ring.  Copies complete
+// in order, so "at most k tiles in flight" means tiles 0 .. issued-k-1 have landed: after
+// an issue the loader waits with k = AHEAD; whenever it cannot issue (ring full, or the
+// whole program issued) it publishes the oldest unpublished tile with the exact count.
+// `land` is the decoder's progress: when it publishes tile t the raw words of tiles 0 .. t+1
+// are in its registers, so the staging slot of tile i is certainly free once land >= i + 1.
+template <int F, bool EXTRA, int AHEAD>
+__device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int RS,
+                                            const int *land, int *rland, int lane) {
+  constexpr int OPS = DmaOps<F, EXTRA>::value;
+  static_assert(OPS * AHEAD <= 63, "vmcnt is 6 bits");
+  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
+  int issued = min(n_tiles, RS);  // loader_start issued these
+  uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
+  int freed = 0;                  // copy of the decoder's counter
+  int pub = 0;                    // tiles published in rland
+  // nothing to issue right now: wait until half of the unpublished tiles have landed and
+  // publish those (then half of the rest, ...)
+  auto publish_some = [&]() {
+    const int keep = (issued - pub - 1) >> 1;  // tiles that may stay in flight
+    wait_tiles_in_flight<OPS, AHEAD>(keep);
+    pub = issued - keep;
+    lds_flag_store(rland, pub);
+  };
+  while (issued < n_tiles) {
+    if (__builtin_expect(issued - freed >= RS, 0)) {  // ring full: look at the decoder's progress
+      freed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      if (issued - freed >= RS) {
+        if (pub < issued) publish_some();
+        else __builtin_amdgcn_s_sleep(1);
       }
+      continue;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tile_issue<F, EXTRA>(g, perm, issued, rb, lane);
+    ++issued;
+    rb = (rb + RB == raw_end) ? raw_base : rb + RB;
+    if (issued - pub > AHEAD) {
+      vm_wait<OPS * AHEAD>();
+      pub = issued - AHEAD;
+      lds_flag_store(rland, pub);
+    }
   }
-};
+  while (pub < n_tiles) publish_some();
+}
 
 // ---- decoder wave -----------------------------------------------------------------
 // flags: land = tiles 0 .. land-1 are decoded and in the ring (written here),
@@ -582,7 +426,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
       tile_issue<F, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
       ++issue_next;
       rb_issue = (rb_issue + RB == raw_end) ? raw_base : rb_issue + RB;
-      vm_wait<(SELF ? OPS * AHEAD : 0)>();  // (the self-loading flavours keep OPS * AHEAD <= 63)
+      vm_wait<OPS * AHEAD>();
       return;
     }
     while (__builtin_expect(landed < need, 0)) {
@@ -592,14 +436,8 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     asm volatile("" ::: "memory");
   };
   auto gather_weights = [&](const RawRegs<U, EXTRA> &w, v2f (&tw)[U]) {
-#ifdef NFST_ABL_DEC_NOGATHER  // (ablation builds only)
-#pragma unroll
-    for (int j = 0; j < U; ++j) tw[j] = v2f{0.5f, __int_as_float((int)w.lab8[j] & 1)};
-    (void)th_base;
-#else
 #pragma unroll
     for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + w.lab8[j]);
-#endif
   };
   // iteration t: `cur` = raw words of tile t, `tw` = its label weights (LDS gathers issued
   // one iteration earlier); fetches the raw words of tile t+1 into `nxt` and, at the end,
@@ -655,14 +493,6 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     sb = (sb + SB == ring_end) ? ring_base : sb + SB;
     gather_weights(nxt, twn);
   };
-#ifdef NFST_ABL_DEC_PASS  // (ablation builds only: the decoder only hands tiles on)
-  for (int t = 0; t < n_tiles; ++t) {
-    wait_raw(min(t + 2, n_tiles));
-    while (t - freed >= R) freed = __builtin_amdgcn_readfirstlane(lds_flag_load(prog));
-    lds_flag_store(land, t + 1);
-  }
-  (void)step; (void)raw_base;
-#else
   RawRegs<U, EXTRA> ra, rbb;
   v2f ta[U], tb[U];
   wait_raw(1);
@@ -674,7 +504,6 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     if (t + 1 >= n_tiles) break;
     step(t + 1, rbb, tb, ra, ta);
   }
-#endif
   if (SELF) vm_wait<0>();  // nothing of the staging ring stays in flight
 }
 
@@ -715,7 +544,7 @@ __device__ __forceinline__ void dec_fetch(uint32_t sb, int lane, TileDec<U> &d) 
 // tile's wave-uniform flags to a scalar register.
 template <int U, bool WIDE>
 __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land,
-                                           uint32_t trash, int lane) {
+                                           int lane) {
   if (n_tiles <= 0) return;
   constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;  // bytes per ring slot
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
@@ -729,7 +558,6 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   };
   uint32_t sb = ring_base;  // slot of the tile that is fetched next
   int land_peek = 0;        // the decoder's counter as of the previous iteration (per-lane copy of the LDS word)
-  int ref = 0;              // reference exponent of tile_math (wave-uniform)
   // iteration T: `cur` = tile T with its uniform flags in `cu`; `nxt` receives tile T+1
   auto step = [&](int T, const TileDec<U> &cur, uint32_t cu, TileDec<U> &nxt, uint32_t &cu_nxt) {
     // --- operand gathers: the head of the dependency chain
@@ -748,20 +576,47 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
     dec_fetch<U>(sb, lane, nxt);
     land_peek = lds_flag_load(land);
     asm volatile("" ::: "memory");
+    // --- what only needs the tile's control word: stage masks (lanes whose state owns
+    // more than 2^s lanes), leader lanes, store address
     const uint32_t w0 = cur.w0;
+    const int gl = (int)((w0 >> 20) & 7u);
+    lds_v2f *dst = (lds_v2f *)(uintptr_t)(w0 & 0xfffffu);
+    const bool leader = (int)w0 < 0;
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
+                   m2 = __builtin_amdgcn_ballot_w64(gl > 2);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // --- products, sum, reduce over the state's lanes, normalise, store.  Only programs the packer
-    // marked WIDE have tiles with groups of more than 8 lanes (flagged wave-uniformly).
-#ifndef NFST_ABL_SWEEP_NOMATH  // (ablation builds only: what the decoder and loader sustain without the sweep's work)
-    float mw[U];
-    int ew[U];
+    // --- this lane's partial sum with one shared exponent
+    float mt[U];
+    int et[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) { mw[j] = cur.tw[j].x; ew[j] = __float_as_int(cur.tw[j].y); }
-    tile_math<U, WIDE>(mw, ew, vv, w0, w0 & 0xfffffu, trash, WIDE && (cu & (1u << 25)) != 0, ref);
-#else
-    if (w0 == 0x12345u) *(lds_v2f *)(uintptr_t)trash = vv[0];
-#endif
+    for (int j = 0; j < U; ++j) {
+      mt[j] = cur.tw[j].x * vv[j].x;
+      et[j] = __float_as_int(cur.tw[j].y) + __float_as_int(vv[j].y);
+    }
+    int E = et[0];
+#pragma unroll
+    for (int j = 1; j < U; ++j) E = max(E, et[j]);
+    float M = ldexpf(mt[0], et[0] - E);
+#pragma unroll
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], et[j] - E);
+    // --- reduce over the state's lanes (max of exponents, one rescale, sum), normalise,
+    // store.  Groups of up to 8 lanes run three stages under execution masks (a stage
+    // nobody takes part in is an empty mask).  Only programs the packer marked WIDE have
+    // tiles with larger groups (flagged wave-uniformly); those take the general path.
+    if (WIDE && __builtin_expect((cu & (1u << 25)) != 0, 0)) {
+      seg_reduce_n<6>(M, E, gl);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    } else {
+      seg_reduce_exec<3>(M, E, m0, m1, m2);
+      if (leader) {
+        const float2 r = me_pack(M, E);
+        *dst = v2f{r.x, r.y};
+      }
+    }
     // tiles 0 .. T+1 are consumed: the words of tile T+1 were read above
     lds_flag_store(prog, T + 2);  // every tile: the decoder's hand-shake latency matters more than the store
     asm volatile("" ::: "memory");
@@ -781,127 +636,34 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   }
 }
 
-// ---- direct sweep: no decoder wave, no decoded ring -------------------------------------
-// With more lattices than CUs the step is bound by the instructions a CU issues, not by one wave's
-// dependency chain: the decoder wave and the LDS round trip of the decoded tile (13 words per lane
-// written and read back) cost more instructions than they take off the sweep wave.  Here the sweep
-// wave does everything itself -- it keeps AHEAD tiles of its program in flight (LDS-DMA into a ring
-// of AHEAD + 1 staging slots), unpacks the raw tile of the next iteration and gathers its label
-// weights in the shadow of the current tile's operand gathers.  A workgroup then needs two busy
-// waves and no decoded rings, so three workgroups share a CU's LDS instead of two.
-template <int F, bool EXTRA, bool WIDE, int AHEAD>
-__device__ __forceinline__ void tile_sweep_direct(int n_tiles, const uint32_t *g, const int32_t *perm, uint32_t *raw,
-                                                  const float2 *val, const float2 *th_, uint32_t trash, int lane) {
-  if (n_tiles <= 0) { vm_wait<0>(); return; }
-  constexpr int U = fmt_u(F);
-  constexpr int OPS = DmaOps<F, EXTRA>::value;
-  constexpr int RS = AHEAD + 1;
-  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
-  const uint32_t th_base = lds_addr(th_), val_base = lds_addr(val);
-  const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
-  uint32_t rb = raw_base;                     // staging slot of the tile whose raw words are fetched next
-  uint32_t rb_issue = raw_base + AHEAD * RB;  // staging slot of the tile issued next
-  int issue_next = AHEAD;
-  int ref = 0;  // reference exponent of tile_math (wave-uniform)
-  const int last = n_tiles - 1;
-  // one more tile goes in flight (past the end the last tile is copied again into a slot nobody
-  // reads: the count stays exact), then at most AHEAD are: the oldest has landed; its raw words are
-  // fetched.  The slot the NEXT call overwrites is the one read here: the caller consumes `w`
-  // (label-weight gathers) before it calls again.
-  auto fetch_raw = [&](RawRegs<U, EXTRA> &w) {
-    tile_issue<F, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
-    ++issue_next;
-    rb_issue = (rb_issue + RB == raw_end) ? raw_base : rb_issue + RB;
-    vm_wait<OPS * AHEAD>();
-    raw_fetch<F, EXTRA>(rb, lane, w);
-    rb = (rb + RB == raw_end) ? raw_base : rb + RB;
-  };
-  auto gather_weights = [&](const RawRegs<U, EXTRA> &w, v2f (&tw)[U]) {
-#pragma unroll
-    for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + w.lab8[j]);
-  };
-  // iteration T: `cur` = raw words of tile T, `tw` = its label weights (gathers issued one iteration
-  // earlier); `nxt` / `twn` receive tile T+1
-  auto step = [&](const RawRegs<U, EXTRA> &cur, v2f (&tw)[U], RawRegs<U, EXTRA> &nxt, v2f (&twn)[U]) {
-    v2f vv[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)(cur.opoff[j] + val_base);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the gathers
-    fetch_raw(nxt);
-    asm volatile("" ::: "memory");
-    const uint32_t ctl = cur.ctl;
-    float mw[U];
-    int ew[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      mw[j] = tw[j].x;
-      ew[j] = __float_as_int(tw[j].y);
-      if (EXTRA) {  // per-arc extras arrive in slot order with the tile
-        const ME x = exp_split(__int_as_float(cur.pm[j]));
-        mw[j] *= x.m;
-        ew[j] += x.e;
-      }
-    }
-    tile_math<U, WIDE>(mw, ew, vv, ctl, (ctl & 0xffffu) + val_base, trash,
-                       WIDE && ((__builtin_amdgcn_readfirstlane(ctl) >> 25) & 1u), ref);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    gather_weights(nxt, twn);
-  };
-  RawRegs<U, EXTRA> ra, rbb;
-  v2f ta[U], tb[U];
-  fetch_raw(ra);
-  gather_weights(ra, ta);
-  // two iterations per trip so that the register roles alternate without copies
-  for (int T = 0; T < n_tiles; T += 2) {
-    step(ra, ta, rbb, tb);
-    if (T + 1 >= n_tiles) break;
-    step(rbb, tb, ra, ta);
-  }
-  vm_wait<0>();  // nothing of the staging ring stays in flight
-}
-
-template <bool EXTRA, int AHEAD>
-__device__ __forceinline__ void run_sweep_direct(int U, bool wide, uint32_t *raw, const uint32_t *g, const int32_t *perm,
-                                                 int n_tiles, float2 *val, const float2 *th, uint32_t trash, int lane) {
-  if (wide) {
-    if (U == 8) tile_sweep_direct<8, EXTRA, true, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-    else if (U == 4) tile_sweep_direct<4, EXTRA, true, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-    else if (U == 2) tile_sweep_direct<2, EXTRA, true, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-    else tile_sweep_direct<1, EXTRA, true, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-  } else {
-    if (U == 8) tile_sweep_direct<8, EXTRA, false, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-    else if (U == 4) tile_sweep_direct<4, EXTRA, false, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-    else if (U == 2) tile_sweep_direct<2, EXTRA, false, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-    else tile_sweep_direct<1, EXTRA, false, AHEAD>(n_tiles, g, perm, raw, val, th, trash, lane);
-  }
-}
-
 // role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder.
 // flags: [0] prog [1] land [2] rland
 template <bool EXTRA, bool SELF, int AHEAD>
 __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *raw, int RS, const uint32_t *g,
                                           const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
-                                          float2 *val, const float2 *th, const Extra ex, uint32_t trash, int lane,
-                                          int burst = 1) {
+                                          float2 *val, const float2 *th, const Extra ex, int lane) {
   int *prog = flags, *land = flags + 1, *rland = flags + 2;
   if (role == 0) {
     if (U == 8) U = 4;  // the sweep only sees decoded tiles
     if (wide) {
-      if (U == 4) tile_sweep<4, true>(n_tiles, ring, R, prog, land, trash, lane);
-      else if (U == 2) tile_sweep<2, true>(n_tiles, ring, R, prog, land, trash, lane);
-      else tile_sweep<1, true>(n_tiles, ring, R, prog, land, trash, lane);
+      if (U == 4) tile_sweep<4, true>(n_tiles, ring, R, prog, land, lane);
+      else if (U == 2) tile_sweep<2, true>(n_tiles, ring, R, prog, land, lane);
+      else tile_sweep<1, true>(n_tiles, ring, R, prog, land, lane);
     } else {
-      if (U == 4) tile_sweep<4, false>(n_tiles, ring, R, prog, land, trash, lane);
-      else if (U == 2) tile_sweep<2, false>(n_tiles, ring, R, prog, land, trash, lane);
-      else tile_sweep<1, false>(n_tiles, ring, R, prog, land, trash, lane);
+      if (U == 4) tile_sweep<4, false>(n_tiles, ring, R, prog, land, lane);
+      else if (U == 2) tile_sweep<2, false>(n_tiles, ring, R, prog, land, lane);
+      else tile_sweep<1, false>(n_tiles, ring, R, prog, land, lane);
     }
   } else if (role == 1) {
     if (U == 8) tile_decoder<8, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
     else if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
     else if (U == 2) tile_decoder<2, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
     else tile_decoder<1, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
+  } else if (!SELF) {
+    if (U == 8) tile_loader<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else if (U == 2) tile_loader<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    else tile_loader<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
   }
 }
 
