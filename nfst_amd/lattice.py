@@ -10,6 +10,7 @@ HIP kernels consume.  torch is used for device memory only.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import Optional, Sequence
 
 import numpy as np
@@ -19,8 +20,21 @@ from . import _lib
 from ._lib import lib, check
 
 
+_warned_d2h = False
+
+
 def _host(a, dtype) -> np.ndarray:
+    """The packer runs on the host.  Tables that already live on the GPU (the reference's trainer moves
+    the collated batch there before ``set_masks``) are copied back first -- 5 MB per 2k-state lattice
+    at V = 256, far more than the step itself costs; said once, not done silently: pack in the
+    DataLoader workers instead (``io.load_packed`` / ``io.collate_packed``, section 8f-1)."""
+    global _warned_d2h
     if isinstance(a, torch.Tensor):
+        if a.is_cuda and not _warned_d2h:
+            _warned_d2h = True
+            warnings.warn(f"nfst_amd: dense lattice tables on {a.device} are copied to the host for packing "
+                          f"({a.numel() * a.element_size() / 1e6:.1f} MB for this tensor); keep the tables on the host, or pack "
+                          "per example in the data loader (nfst_amd.io.load_packed / collate_packed)", stacklevel=3)
         a = a.detach().cpu().numpy()
     return np.ascontiguousarray(a, dtype=dtype)
 

@@ -409,6 +409,11 @@ def backward_neural(lat: LatticeBatch, emb: torch.Tensor, Wx: torch.Tensor, Wh: 
     one [V, H] x [H, H] product made here (a plain library GEMM); everything that depends on the
     lattice runs in the kernel."""
     _need_gpu(lat)
+    if torch.is_grad_enabled() and any(isinstance(p, torch.Tensor) and p.requires_grad for p in (emb, Wx, Wh, W, bias)):
+        # forward only: the reference differentiates log q through compute_beta() (tune_proposal,
+        # lightning.py:339-406); no backward kernel exists yet, and a silent zero gradient would be worse
+        raise RuntimeError("nfst_amd: backward_neural has no backward pass yet (forward only); call it under "
+                           "torch.no_grad() or detach the parameters")
     f32 = dict(device=lat.device, dtype=torch.float32)
     emb, Wx, Wh, bias = emb.to(**f32), Wx.to(**f32), Wh.to(**f32), bias.to(**f32)
     w = W.to(**f32).reshape(-1).contiguous()
