@@ -48,6 +48,8 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  // this thread's label score: requested before anything waits for the meta record
+  const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *beta = lds;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
     loader_start<EXTRA>(m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_extras, m.bwd_tiles, raw, RS, lane);
   }
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
-  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
   __syncthreads();
   int *flags = (int *)(ring + LdsPlan::sweep_words(R, RS, EXTRA));
   if (tid == 0) {
@@ -117,6 +119,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  // this thread's label score: requested before anything waits for the meta record
+  const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
   float2 *alpha = lds;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
     beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   }
-  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT);
+  load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   __syncthreads();
   int *flags = (int *)(ring + 2 * LdsPlan::sweep_words(R, RS, EXTRA));
@@ -215,22 +219,19 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     }
     if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
   };
-  if (kPre > 0 && tid >= kSweepThreads) {
-    if (want_post) {
+  if (kPre > 0 && tid >= kSweepThreads && want_post) {
 #pragma unroll
-      for (int u = 0; u < kPre; ++u) {
-        const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
-        if (a < v_end) do_group(psd[u], plb[u], a);
-      }
+    for (int u = 0; u < kPre; ++u) {
+      const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
+      if (a < v_end) do_group(psd[u], plb[u], a);
     }
-  } else {
-    // the sweep waves (all waves when there are no helpers) write the row outputs
-    constexpr int RT = (kPre > 0) ? kSweepThreads : NT;
-    for (int i = tid; i < m.n_rows; i += RT) {
-      if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
-      if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
-      if (beta_me) beta_me[m.row_off + i] = beta[i];
-    }
+  }
+  // the row outputs: every thread (the sweep waves start here, the others come when their preloaded
+  // arc groups are done)
+  for (int i = tid; i < m.n_rows; i += NT) {
+    if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
+    if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
+    if (beta_me) beta_me[m.row_off + i] = beta[i];
   }
   if (want_post) {
     // the arc groups that were not preloaded: kPB groups per iteration, all loads issued

@@ -43,14 +43,18 @@ __device__ __forceinline__ float2 me_pack(float M, int E) {
   return make_float2(mant, __int_as_float(max(E + ex, kEZero)));  // saturates at 2^(-2^28): no wrap-around
 }
 
-// natural log of an (m, e) pair in float64 / float32
+// natural log of an (m, e) pair.  float64: log(m) in float32 (m in [0.5, 1): |log m| <= 0.7, so one
+// float32 ulp is 6e-8 absolute -- below what the float32 mantissa arithmetic of the sweeps leaves)
+// plus e * ln 2 in float64; no double-precision log on the kernel's tail.  float32: two fused
+// multiply-adds with ln 2 split in two (the product with the high part is exact for |e| < 2^11).
 __device__ __forceinline__ double me_log64(float2 v) {
   if (!(v.x > 0.0f)) return -__builtin_huge_val();
-  return log((double)v.x) + (double)__float_as_int(v.y) * 0.693147180559945309417232;
+  return (double)logf(v.x) + (double)__float_as_int(v.y) * 0.693147180559945309417232;
 }
 __device__ __forceinline__ float me_log32(float2 v) {
   if (!(v.x > 0.0f)) return kNegInf;
-  return (float)((double)logf(v.x) + (double)__float_as_int(v.y) * 0.693147180559945309417232);
+  const float e = (float)__float_as_int(v.y);
+  return fmaf(e, 0.693145751953125f, fmaf(e, 1.42860682030941723e-6f, logf(v.x)));
 }
 
 struct Meta {

@@ -667,11 +667,12 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
   }
 }
 
+// `first` = theta[tid] loaded by the caller at kernel entry (beside the meta record, not behind it)
 __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64_t stride, int b,
-                                           int V, int tid, int nt) {
+                                           int V, int tid, int nt, float first) {
   const float *t = theta + (size_t)stride * b;
   for (int l = tid; l < V; l += nt) {
-    ME x = exp_split(t[l]);
+    ME x = exp_split(l == tid ? first : t[l]);
     th[l] = make_float2(x.m, __int_as_float(x.e));
   }
   if (tid == 0) {
