@@ -110,13 +110,17 @@ extern "C" {
  * nonzero(emission) / transition.  The sink's pad self loop is included.
  * Tile programs (engine-private): the level-scheduled sweeps, DESIGN.md section 3.
  */
+/* nfst_batch.reserved0 bit: every tile program of the batch is in the compact format (code 8): the
+ * fused sweep kernels apply (set by the packer; LatticeBatch.concat keeps it if all parts have it) */
+#define NFST_BATCH_ALL_COMPACT 1
+
 typedef struct nfst_batch {
   int32_t n_lattices;
   int32_t vocab;
   int32_t max_rows;        /* max over the batch of the LDS rows a lattice needs: n_rows + scratch rows of its tile programs */
   int32_t max_tiles;       /* max tiles of one program over the batch */
   int32_t weighted;        /* arc_w holds the table's float weights */
-  int32_t reserved0;
+  int32_t reserved0;       /* flags: NFST_BATCH_ALL_COMPACT */
   int64_t total_rows;
   int64_t total_arcs;
   int64_t total_dp_arcs;

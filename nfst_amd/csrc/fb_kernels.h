@@ -28,7 +28,7 @@ struct LdsPlan {
     return (int64_t)R * kSlotWords + (int64_t)RS * (extra ? kRawWordsX : kRawWords);
   }
   __host__ __device__ int64_t fb_bytes(int R, int RS, bool extra) const {
-    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * sweep_words(R, RS, extra) * 4 + 32;
+    return ((int64_t)2 * rows2 + v2) * 8 + (int64_t)v4 * 4 + 2 * sweep_words(R, RS, extra) * 4 + 32 + 1024;  // + 8 flag words + 64 x 8 bytes of trash per fused sweep
   }
   __host__ __device__ int64_t bwd_bytes(int R, int RS, bool extra) const {
     return ((int64_t)rows2 + v2) * 8 + sweep_words(R, RS, extra) * 4 + 16;
@@ -111,7 +111,9 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // Wave 0 runs the beta sweep and wave 1 the alpha sweep, concurrently and without any
 // synchronisation between them, fed by waves 2 and 3; after the one barrier that
 // follows every wave of the block streams canonical arcs for the posteriors.
-template <int NT, bool EXTRA>
+// FUSED: waves 0 / 1 load, decode and sweep by themselves (FusedSweep, tile_pipeline.h): no loader,
+// no decoder, no rings; every program of the batch is compact and there are no per-arc extras.
+template <int NT, bool EXTRA, bool FUSED = false>
 __global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, int R, int RS, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, double *__restrict__ logz_total, int total_slot,
@@ -147,7 +149,10 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // staging ring); otherwise two workgroups share a CU and the decoders load for themselves
   constexpr bool kSelf = NT != 1024;
   constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
-  if (kSelf) {
+  static_assert(!(FUSED && EXTRA), "the fused sweep takes no per-arc extras");
+  if (FUSED) {
+    if (wv < 2) FusedSweep<false>::start(my_prog, my_tiles, lane);  // (start() does not depend on WIDE)
+  } else if (kSelf) {
     if (wv == 2 || wv == 3) self_start<EXTRA, kAhead>(my_u, my_prog, my_perm, my_tiles, my_raw, lane);
   } else if (wv == 6 || wv == 7) {
     loader_start<EXTRA>(my_u, my_prog, my_perm, my_tiles, my_raw, RS, lane);
@@ -191,7 +196,13 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     }
   }
   // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 6 / 7 load for them
-  if (wv < 4 || (!kSelf && (wv == 6 || wv == 7)))
+  if constexpr (FUSED) {
+    if (wv < 2) {
+      const uint32_t trash = lds_addr(flags + 8) + (bwd_side ? 0 : 512) + lane * 8;
+      if (my_wide) FusedSweep<true>::run(my_prog, my_tiles, bwd_side ? beta : alpha, th, trash, lane);
+      else FusedSweep<false>::run(my_prog, my_tiles, bwd_side ? beta : alpha, th, trash, lane);
+    }
+  } else if (wv < 4 || (!kSelf && (wv == 6 || wv == 7)))
     run_sweep<EXTRA, kSelf, kAhead>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog, my_perm, my_tiles, my_ring, R,
                      bwd_side ? flags : flags + 4, bwd_side ? beta : alpha, th, ex, lane);
   __syncthreads();

@@ -185,7 +185,14 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   const LdsPlan plan(lat->max_rows, lat->vocab);
   const int cus = cu_count();
   RingCfg cfg;
-  if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
+  // every program compact and no per-arc extras: the fused sweeps (no rings at all)
+  const char *no_fused = getenv("NFST_NO_FUSED");  // (A/B measurements: "1" selects the loader / decoder / sweep pipeline)
+  // Measured (profiles/r02_ab_fused.txt): 227 against 164 G arcs/s at 1024 lattices, 210 against 160 at 2048,
+  // equal at 512; with one lattice per CU the three-wave pipeline is 10 % faster (46.8 against 51.8 us).
+  const bool fused = !extra && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && lat->n_lattices > cus &&
+                     !(no_fused && no_fused[0] == '1');
+  if (fused) cfg = {0, 0, lat->n_lattices > cus};
+  else if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
   if (extra) {  // slot-ordered extras of both programs
     if (!scores->slot_ws) return NFST_ERR_ARG;
     const int64_t n = lat->fwd_slots + lat->bwd_slots;
@@ -203,12 +210,26 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
                        (int)total_slot, posterior,                                                      \
                        grad_theta, (float2 *)beta_me);                                                  \
   }
+#define NFST_LAUNCH_FUSED(NT)                                                                            \
+  {                                                                                                     \
+    if ((rc = set_lds(k_forward_backward<NT, false, true>, lds))) return rc;                            \
+    hipLaunchKernelGGL((k_forward_backward<NT, false, true>), dim3(lat->n_lattices), dim3(NT), (size_t)lds, \
+                       (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, logz_total,    \
+                       (int)total_slot, posterior, grad_theta, (float2 *)beta_me);                      \
+  }
   // 1024 threads: loaders + decoders + sweeps and 10 more waves for the posterior pass (deep);
   // 512 / 256 threads: self-loading decoders + sweeps, two workgroups per CU when they fit
-  if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
+  if (fused) {
+    if (lds > kMaxLds) return NFST_ERR_LIMIT;
+    // (512 threads at most: with 1024 the 128 registers a lane may have leave hipcc 64 VGPRs beside the
+    // fused sweep's 32 AGPRs, and it then spills into AGPRs -- into the ones the sweep stages tiles in)
+    if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FUSED(512)
+    else NFST_LAUNCH_FUSED(256)
+  } else if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
   else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
   else { if (extra) NFST_LAUNCH_FB(256, true) else NFST_LAUNCH_FB(256, false) }
 #undef NFST_LAUNCH_FB
+#undef NFST_LAUNCH_FUSED
   return hip_status(hipGetLastError());
 }
 

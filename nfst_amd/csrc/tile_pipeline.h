@@ -179,6 +179,205 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
+// ---- fused sweep: one wave loads, decodes and sweeps ---------------------------------------
+// Round-2 measurements: the loader -> decoder -> sweep pipeline spends most
+// of a tile's 267 ns in its two hand-offs through LDS (an empty pipeline already needs 177 ns per
+// tile), and an LDS access of a wave waits for that wave's own LDS-DMAs, so a wave cannot both
+// stream by DMA and talk through LDS.  The fused sweep has no hand-off: ONE wave per direction
+//   * keeps kFusedDepth tiles of its program in flight with plain global loads whose destinations
+//     are accumulation registers (AGPRs) the compiler never allocates: the load and, kFusedDepth
+//     tiles later, "wait + move to VGPRs" are single asm statements, so no compiler-made copy can
+//     touch a register before its data has arrived (hipcc did copy VGPR destinations of asm loads
+//     in front of a hand-placed wait);
+//   * unpacks the raw tile of the NEXT iteration and gathers its label weights in the shadow of the
+//     current tile's operand gathers;
+//   * sums and reduces with tile_math (below).
+// No staging ring, no decoded ring, no flags: a workgroup's LDS is alpha, beta and the label table,
+// so four workgroups share a CU when there are more lattices than CUs.  Compact tile format only
+// (16 bytes per lane: the common case); other formats and per-arc extras run the pipeline flavours.
+constexpr int kFusedDepth = 8;
+#define NFST_AGPR_SLOTS(X) X(0, "a[0:3]", "a0", "a1", "a2", "a3") X(1, "a[4:7]", "a4", "a5", "a6", "a7") \
+  X(2, "a[8:11]", "a8", "a9", "a10", "a11") X(3, "a[12:15]", "a12", "a13", "a14", "a15")                  \
+  X(4, "a[16:19]", "a16", "a17", "a18", "a19") X(5, "a[20:23]", "a20", "a21", "a22", "a23")              \
+  X(6, "a[24:27]", "a24", "a25", "a26", "a27") X(7, "a[28:31]", "a28", "a29", "a30", "a31")
+template <int J>
+__device__ __forceinline__ void agpr_load(const void *p) {  // 16 bytes per lane -> AGPR set J
+#define NFST_X(K, R, A0, A1, A2, A3) \
+  if (J == K) asm volatile("global_load_dwordx4 " R ", %0, off nt" ::"v"(p) : "memory", A0, A1, A2, A3);
+  NFST_AGPR_SLOTS(NFST_X)
+#undef NFST_X
+}
+template <int J, int N>
+__device__ __forceinline__ v4u agpr_take() {  // at most N loads stay in flight; AGPR set J -> VGPRs
+  v4u r;
+#define NFST_X(K, R, A0, A1, A2, A3)                                                                                      \
+  if (J == K)                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, " A0 "\n\tv_accvgpr_read_b32 %1, " A1                     \
+                 "\n\tv_accvgpr_read_b32 %2, " A2 "\n\tv_accvgpr_read_b32 %3, " A3                                        \
+                 : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w)                                                             \
+                 : "n"(N)                                                                                                 \
+                 : "memory");
+  NFST_AGPR_SLOTS(NFST_X)
+#undef NFST_X
+  return r;
+}
+
+// terms of a state aligned to a stale wave-uniform exponent, summed over the state's lanes by three
+// v_fmac_f32_dpp with a 0 / 1 multiplier (no execution-mask changes)
+__device__ __forceinline__ float seg_sum_fmac3(float M, float gf) {
+  float k0, k1, k2;
+  asm volatile(
+      "v_max_f32_e64 %[k0], %[g], %[g] clamp\n\t"
+      "v_add_f32_e64 %[k1], %[g], -1.0 clamp\n\t"
+      "v_fmac_f32_dpp %[m], %[m], %[k0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_e64 %[k2], %[g], -2.0 clamp\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %[m], %[m], %[k1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %[m], %[m], %[k2] row_half_mirror row_mask:0xf bank_mask:0xf"
+      : [m] "+v"(M), [k0] "=&v"(k0), [k1] "=&v"(k1), [k2] "=&v"(k2)
+      : [g] "v"(gf));
+  return M;
+}
+
+// One tile of a sum-product sweep: this lane's products, their sum, the sum over the state's
+// lanes, normalisation, the leaders' stores.  `trash` is a per-lane LDS location the other lanes store
+// to (no execution-mask change, no branch).
+// Fast path (groups of up to 8 lanes).  Scaling by a power of two is exact, so the terms of a state
+// may be aligned to ANY common exponent that keeps them inside float32's range, not only to their
+// maximum.  The reference `ref` is wave-uniform and one tile old (the exponent lane 0 ended the
+// previous tile with: values drift by a few binary orders per level): a term is one multiply, one
+// three-operand add and one ldexp; no maximum of exponents, no rescale, and the K_s multiplier of
+// v_fmac_f32_dpp (1 if the state owns more than 2^s lanes, else 0; partners always agree because
+// groups are 2^g-aligned) replaces the execution masks.  A tile in which some lane's largest
+// non-zero term lies more than 2^64 away from the reference is redone by the exact path (maximum of
+// exponents over the state's lanes first); everywhere else the two paths give the same bits
+// (terms more than 2^60 below a lane's largest cannot change a float32 sum).  Exact zeros carry the
+// exponent kEZero (about -2^28): a lane whose terms are all zero is recognised by that and never
+// forces the exact path.
+template <int U, bool WIDE>
+__device__ __forceinline__ void tile_math(const v2f (&tw)[U], const v2f (&vv)[U], uint32_t ctl, uint32_t dst_addr,
+                                          uint32_t trash, bool wide_tile, int &ref) {
+  const int gl = (int)((ctl >> 20) & 7u);
+  const bool leader = (int)ctl < 0;
+  const int nref = -ref;
+  float mt[U];
+  int d[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    mt[j] = tw[j].x * vv[j].x;
+    d[j] = __float_as_int(tw[j].y) + __float_as_int(vv[j].y) + nref;
+  }
+  int dmax = d[0];
+#pragma unroll
+  for (int j = 1; j < U; ++j) dmax = max(dmax, d[j]);
+  float M = ldexpf(mt[0], d[0]);
+#pragma unroll
+  for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j]);
+  constexpr int kZeroish = -(1 << 27);
+  const bool bad = ((uint32_t)(dmax + 64) > 128u) & (dmax > kZeroish);
+  int E = ref;
+  // the next tile's reference: where lane 0 stands now (kept if lane 0 holds nothing)
+  const int e0 = __builtin_amdgcn_readfirstlane(dmax);
+  const int ref_old = ref;
+  ref = (e0 > kZeroish) ? e0 + ref_old : ref_old;
+  if (__builtin_expect((WIDE && wide_tile) || __builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+    // exact path: this lane's sum relative to its largest term, then the maximum over the state's lanes
+    M = ldexpf(mt[0], d[0] - dmax);
+#pragma unroll
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j] - dmax);
+    E = dmax + ref_old;
+    if (WIDE && wide_tile) {
+      seg_reduce_n<6>(M, E, gl);
+    } else {
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(gl > 0), m1 = __builtin_amdgcn_ballot_w64(gl > 1),
+                     m2 = __builtin_amdgcn_ballot_w64(gl > 2);
+      seg_reduce_exec<3>(M, E, m0, m1, m2);
+    }
+  } else {
+    M = seg_sum_fmac3(M, (float)gl);
+    E = (M == 0.0f) ? kEZero : E;  // an exact zero keeps the exponent that never wins a maximum
+  }
+  const float2 r = me_pack(M, E);
+  *(lds_v2f *)(uintptr_t)(leader ? dst_addr : trash) = v2f{r.x, r.y};  // trash: this lane's own 8 bytes
+}
+
+template <bool WIDE>
+struct FusedSweep {
+  static constexpr int K = kFusedDepth;
+  struct Dec { uint32_t ctl; uint32_t opa[4]; uint32_t lab8[4]; };  // unpacked tile: control word, operand LDS addresses, 8 x label
+  // tiles 0 .. K-1 go in flight (short programs load their last tile again: the count stays K)
+  __device__ __forceinline__ static void start(const uint32_t *g, int n_tiles, int lane) {
+    const int last = max(n_tiles - 1, 0);
+    const uint32_t *p = g + lane * 4;
+    agpr_load<0>(p + (size_t)min(0, last) * 256); agpr_load<1>(p + (size_t)min(1, last) * 256);
+    agpr_load<2>(p + (size_t)min(2, last) * 256); agpr_load<3>(p + (size_t)min(3, last) * 256);
+    agpr_load<4>(p + (size_t)min(4, last) * 256); agpr_load<5>(p + (size_t)min(5, last) * 256);
+    agpr_load<6>(p + (size_t)min(6, last) * 256); agpr_load<7>(p + (size_t)min(7, last) * 256);
+  }
+  __device__ __forceinline__ static void unpack(const v4u x, uint32_t val_base, Dec &w) {
+    w.ctl = x.x;
+    const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w.opa[j] = ((r[j] << 3) & 0xfff8u) + val_base;  // state (13 bits) x 8 + the array's base
+      w.lab8[j] = (r[j] >> 10) & 0x3ff8u;             // label (11 bits) x 8
+    }
+  }
+  // the oldest tile in flight (set J) -> w; set J then loads tile `tile + K` (past the end: the last
+  // tile again, never used)
+  template <int J>
+  __device__ __forceinline__ static void take(const uint32_t *g, int tile, int last, int lane, uint32_t val_base, Dec &w) {
+    const v4u x = agpr_take<J, K - 1>();
+    agpr_load<J>(g + (size_t)min(tile + K, last) * 256 + lane * 4);
+    unpack(x, val_base, w);
+  }
+  __device__ __forceinline__ static void run(const uint32_t *g, int n_tiles, const float2 *val, const float2 *th_, uint32_t trash,
+                                             int lane) {
+    if (n_tiles <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    const uint32_t th_base = lds_addr(th_), val_base = lds_addr(val);
+    const int last = n_tiles - 1;
+    int ref = 0;
+    auto gather_weights = [&](const Dec &w, v2f (&tw)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + w.lab8[j]);
+    };
+    // iteration t: `cur` = tile t unpacked, `tw` = its label weights (gathers issued one iteration
+    // earlier); takes tile t+1 into `nxt` and, at the end, issues the gathers of its label weights
+#define NFST_FUSED_STEP(JN, CUR, TW, NXT, TWN)                                                             \
+    {                                                                                                     \
+      v2f vv[4];                                                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)CUR.opa[j];       \
+      asm volatile("" ::: "memory");                                                                      \
+      __builtin_amdgcn_sched_barrier(0);  /* nothing is scheduled in front of the operand gathers */      \
+      take<JN>(g, t + 1, last, lane, val_base, NXT);                                                      \
+      asm volatile("" ::: "memory");                                                                      \
+      tile_math<4, WIDE>(TW, vv, CUR.ctl, (CUR.ctl & 0xffffu) + val_base, trash,                           \
+                         WIDE && ((__builtin_amdgcn_readfirstlane(CUR.ctl) >> 25) & 1u), ref);            \
+      asm volatile("" ::: "memory");                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      gather_weights(NXT, TWN);                                                                           \
+    }
+    Dec da, db;
+    v2f ta[4], tb[4];
+    take<0>(g, 0, last, lane, val_base, da);
+    gather_weights(da, ta);
+    for (int t0 = 0; t0 < n_tiles; t0 += K) {  // K iterations per trip: AGPR sets and register roles are compile-time
+      int t = t0;
+      NFST_FUSED_STEP(1, da, ta, db, tb) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(2, db, tb, da, ta) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(3, da, ta, db, tb) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(4, db, tb, da, ta) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(5, da, ta, db, tb) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(6, db, tb, da, ta) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(7, da, ta, db, tb) if (++t >= n_tiles) break;
+      NFST_FUSED_STEP(0, db, tb, da, ta)
+    }
+#undef NFST_FUSED_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing stays in flight
+  }
+};
+
 // ---- producer / consumer protocol -------------------------------------------------
 // Two LDS words per sweep, both only grow:
 //   land: tiles 0 .. land-1 are decoded and in the ring (written by the decoder)
@@ -558,6 +757,7 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   };
   uint32_t sb = ring_base;  // slot of the tile that is fetched next
   int land_peek = 0;        // the decoder's counter as of the previous iteration (per-lane copy of the LDS word)
+
   // iteration T: `cur` = tile T with its uniform flags in `cu`; `nxt` receives tile T+1
   auto step = [&](int T, const TileDec<U> &cur, uint32_t cu, TileDec<U> &nxt, uint32_t &cu_nxt) {
     // --- operand gathers: the head of the dependency chain

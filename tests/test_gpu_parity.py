@@ -542,12 +542,22 @@ def test_large_lattice_falls_back_to_small_rings(dev):
         assert abs(float(rb.logz64[b]) - o["logZ"]) <= TOL
         cmp_rows(r.logbeta.cpu().numpy()[r0:r0 + l.n_rows], o["logbeta"], tag="large_lattice_logbeta")
         assert rec("large_lattice_post", np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"]))) <= 5e-6
-    # beyond the limit the launch is refused with an error code, not a fault
+    # beyond the limit the launch is refused with an error code, not a fault (the three-wave pipeline: alpha +
+    # beta + the smallest rings of an 8180-state lattice exceed a CU's LDS)
     huge = synth.layered_lattice(6, n_states=8180, avg_degree=4.0, vocab=V, width=32, span=4)
     lat = LatticeBatch.from_synth([huge], device=dev)
     with pytest.raises(_lib.NfstError) as e:
         ops.forward_backward(lat, torch.from_numpy(theta))
     assert e.value.code == -6  # NFST_ERR_LIMIT
+    # the fused sweeps (more lattices than CUs, compact programs) keep no rings: the same lattice fits
+    many = LatticeBatch.concat([LatticeBatch.from_synth([huge], slots_per_lane=4)] + [LatticeBatch.from_synth([small], slots_per_lane=4)] * 300,
+                               device=dev)
+    assert many.reserved0 & 1  # every program compact
+    r = ops.forward_backward(many, torch.from_numpy(theta))
+    o, _ = oracle_fb(huge, theta)
+    assert rec("huge_lattice_fused_logz", abs(float(r.logz64[0]) - o["logZ"])) <= TOL
+    o, _ = oracle_fb(small, theta)
+    assert np.max(np.abs(r.logz64.cpu().numpy()[1:] - o["logZ"])) <= TOL
 
 
 def test_huge_negative_scores_saturate_instead_of_wrapping(dev):
