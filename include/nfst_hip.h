@@ -30,6 +30,7 @@
  *   nfst_proposal_step (+ _backward)   one step of Sampler.stateful_sample on the lattice
  *                                      side (samplers.py:243-297; scorers.py:340-366, 630-690)
  *   nfst_backward_neural               compute_beta with Wh != 0 (scorers.py:692-856)
+ *   nfst_backward_neural_grad          its gradient (tune_proposal, lightning.py:339-406)
  *   nfst_gather_label_scores           WFSTScorer (scorers.py:1671-1687)
  *   nfst_path_logprob (+ _backward)    StaticRNNScorer.evaluate_seq_with_temp
  *                                      gather (scorers.py:1564-1611) and its gradient
@@ -61,7 +62,7 @@
 extern "C" {
 #endif
 
-#define NFST_ABI_VERSION 4
+#define NFST_ABI_VERSION 5
 
 /* error codes */
 #define NFST_OK 0
@@ -367,6 +368,24 @@ int nfst_proposal_step_backward(const nfst_batch *lat, const int64_t *value_stat
 int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid);
 int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh, const float *w,
                          int32_t hid, float *log_beta, float *beta_hat, float *ws, void *stream);
+
+/*
+ * Gradient of nfst_backward_neural: tune_proposal differentiates log q through compute_beta()
+ * (modules/lightning.py:339-406) w.r.t. Wh, Wx, W, beta_bias and the embeddings
+ * (scorers.py:954-970).  Inputs: the forward call's label_x, w, beta_hat and workspace (ws_fwd,
+ * untouched since), wh_t = Wh transposed ([hid (in), hid (out)] row-major), g_log_beta
+ * [total_rows] = dL / d log_beta, g_beta_hat [total_rows, hid] = dL / d beta_hat or NULL.
+ * Outputs: grad_label_x [vocab, hid] and grad_w [hid] ACCUMULATE (float atomics: the caller zeroes
+ * them, the summation order is not fixed); gamma [total_rows, hid] (zeroed by the caller) receives
+ * dL / d (Wh . beta_hat(s)) per state, so that dL/dWh = gamma^T . beta_hat is one library GEMM on
+ * the caller's side.  dL/dWx, dL/dbias and dL/d embeddings follow from grad_label_x through
+ * label_x = emb . Wx^T + bias.  ws: nfst_neural_grad_ws_floats() floats, contents irrelevant.
+ */
+int64_t nfst_neural_grad_ws_floats(const nfst_batch *lat, int32_t hid);
+int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w,
+                              int32_t hid, const float *beta_hat, const float *ws_fwd, const float *g_log_beta,
+                              const float *g_beta_hat, float *gamma, float *grad_label_x, float *grad_w,
+                              float *ws, void *stream);
 
 /* out[a] = theta[(theta_stride * b) + label[a]] (+ arc_w[a]) (+ arc_scores[a]) */
 int nfst_gather_label_scores(const nfst_batch *lat, const nfst_scores *scores, float *out,

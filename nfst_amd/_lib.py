@@ -93,6 +93,8 @@ def _load():
         "nfst_proposal_step_backward": (C.c_int, [BP, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, i32, vp]),
         "nfst_neural_ws_floats": (i64, [BP, i32]),
         "nfst_backward_neural": (C.c_int, [BP, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "nfst_neural_grad_ws_floats": (i64, [BP, i32]),
+        "nfst_backward_neural_grad": (C.c_int, [BP, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "nfst_gather_label_scores": (C.c_int, [BP, SP, vp, vp]),
         "nfst_path_logprob": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, f32, i32, vp, vp]),
         "nfst_path_logprob_backward": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, f32, i32, vp, vp]),

@@ -356,7 +356,7 @@ int nfst_proposal_step_backward(const nfst_batch *lat, const int64_t *value_stat
 
 int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid) {
   if (!lat || hid <= 0) return NFST_ERR_ARG;
-  return 2 * (int64_t)lat->n_lattices * lat->max_rows * hid;
+  return 2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1);
 }
 
 int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh, const float *w, int32_t hid,
@@ -377,6 +377,36 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   else if (hid <= 256) NFST_LAUNCH_NEU(4);
   else NFST_LAUNCH_NEU(8);
 #undef NFST_LAUNCH_NEU
+  return hip_status(hipGetLastError());
+}
+
+int64_t nfst_neural_grad_ws_floats(const nfst_batch *lat, int32_t hid) {
+  if (!lat || hid <= 0) return NFST_ERR_ARG;
+  return 2 * (int64_t)lat->n_lattices * lat->max_rows * hid;
+}
+
+int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w, int32_t hid,
+                              const float *beta_hat, const float *ws_fwd, const float *g_log_beta, const float *g_beta_hat,
+                              float *gamma, float *grad_label_x, float *grad_w, float *ws, void *stream) {
+  int rc = check_batch(lat);
+  if (rc) return rc;
+  if (!label_x || !wh_t || !w || !beta_hat || !ws_fwd || !g_log_beta || !gamma || !grad_label_x || !grad_w || !ws || hid <= 0)
+    return NFST_ERR_ARG;
+  if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
+  if (lat->fwd_slots > 0 && !lat->fwd_perm) return NFST_ERR_ARG;
+  const int64_t lds = NeuGradLds(lat->max_rows, hid).bytes();
+#define NFST_LAUNCH_NEUG(HC)                                                                                       \
+  do {                                                                                                             \
+    if ((rc = set_lds(k_backward_neural_grad<HC>, lds))) return rc;                                                \
+    hipLaunchKernelGGL(k_backward_neural_grad<HC>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,          \
+                       (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, beta_hat, ws_fwd, g_log_beta,         \
+                       g_beta_hat, gamma, grad_label_x, grad_w, ws);                                               \
+  } while (0)
+  if (hid <= 64) NFST_LAUNCH_NEUG(1);
+  else if (hid <= 128) NFST_LAUNCH_NEUG(2);
+  else if (hid <= 256) NFST_LAUNCH_NEUG(4);
+  else NFST_LAUNCH_NEUG(8);
+#undef NFST_LAUNCH_NEUG
   return hip_status(hipGetLastError());
 }
 

@@ -58,6 +58,113 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // 2^-d for d >= 0 (0 when the term is too small to matter)
 __device__ __forceinline__ float neu_scale(int d) { return d > 120 ? 0.0f : __int_as_float((127 - d) << 23); }
 
+// One wave stages a tile of a program for the phases that follow: control words, records as 32-bit
+// words (8 x operand state | label << 16), slot -> canonical arc map, list of group leaders.  Its
+// loads miss to HBM, and a wave's loads complete in order, so they must not sit in front of a
+// computing wave's L2 hits: the last wave of the workgroup stages tile T+1 while the others run
+// phase A of tile T.
+__device__ __forceinline__ void neu_stage_tile(const uint32_t *prog, const int32_t *perm, int F, int T, uint32_t *st, int lane) {
+  const int U = fmt_u(F), ST = fmt_words(F);
+  uint32_t *ctl = st, *rec = st + 64;
+  int *cas = (int *)(st + 320), *lead = (int *)(st + 576), *nlead = (int *)(st + 640);
+  uint32_t c;
+  if (F == 8) {
+    const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
+    c = x.x;
+    const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rec[lane * 4 + j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);
+  } else {
+    c = prog[(size_t)T * ST + lane];
+    for (int j = 0; j < U; ++j) rec[lane + 64 * j] = prog[(size_t)T * ST + 64 + lane + 64 * j];
+  }
+  for (int j = 0; j < U; ++j) cas[lane + 64 * j] = perm[(size_t)T * 64 * U + lane + 64 * j];
+  ctl[lane] = c;
+  const uint64_t leaders = __builtin_amdgcn_ballot_w64((c >> 31) != 0);
+  if (c >> 31) lead[__builtin_popcountll(leaders & ((1ull << lane) - 1))] = lane;
+  if (lane == 0) nlead[0] = __builtin_popcountll(leaders);
+}
+
+// a row another wave of this workgroup wrote earlier in the kernel: read past the CU's vector L1
+// (scratch rows are rewritten level after level, a cached line may be stale)
+__device__ __forceinline__ float neu_load_fresh(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Phase B of a tile: out(s) = M . row(s) for the states the tile finished, 16 of them per pass over
+// the matrix: D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32
+// (v_mfma_f32_16x16x4_f32), one block of 16 columns per wave.  A comes from the LDS rows phase A
+// filled (rows_s; groups beyond kNeuRows are fetched back through row_of), B straight from the
+// matrix (L2), row-major [out, in].  put(state, column, value) stores a result.
+template <class RowOf, class Put>
+__device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, const float *__restrict__ wh, int hid,
+                                            const uint32_t *ctl_s, const int *lead_s, int tid, int wv, int lane,
+                                            RowOf row_of, Put put) {
+  // ---- B: u = Wh . beta_hat for the states this tile wrote, 16 of them per pass over Wh:
+  // D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32, one block of
+  // 16 columns per wave.  A comes from the LDS rows phase A filled, B straight from Wh (L2).
+  for (int g0 = 0; g0 < n_lead; g0 += 16) {
+    const int n = min(16, n_lead - g0);
+    const float *rows = rows_s + (size_t)g0 * hs;
+    if (g0 + 16 > kNeuRows) {  // more groups in the tile than LDS rows: fetch theirs from the workspace
+      __syncthreads();
+      for (int i = tid; i < n * hid; i += kNeuThreads) {
+        const int g = i / hid, h = i - g * hid;
+        const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
+        rows_s[g * hs + h] = neu_load_fresh(row_of(sid) + h);
+      }
+      __syncthreads();
+      rows = rows_s;
+    }
+    const int li = lane & 15, kq = lane >> 4;
+    for (int ct = wv; ct * 16 < hid; ct += kNeuWaves) {
+      const int col = ct * 16 + li;
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      if ((hid & 15) == 0) {
+        const float *bp = wh + (size_t)col * hid + 4 * kq;
+        const float *ap = rows + li * hs + 4 * kq;
+        int h = 0;
+        for (; h + 64 <= hid; h += 64) {  // four 16-byte loads of Wh in flight per lane
+          float4 bq[4], aq[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) bq[d] = *reinterpret_cast<const float4 *>(bp + h + 16 * d);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) aq[d] = *reinterpret_cast<const float4 *>(ap + h + 16 * d);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].x, bq[d].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].y, bq[d].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].z, bq[d].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].w, bq[d].w, acc, 0, 0, 0);
+          }
+        }
+        for (; h < hid; h += 16) {
+          const float4 bq = *reinterpret_cast<const float4 *>(bp + h);
+          const float4 aq = *reinterpret_cast<const float4 *>(ap + h);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq.w, acc, 0, 0, 0);
+        }
+      } else {
+        for (int h = 0; h < hid; h += 4) {  // the LDS rows are zero beyond hid
+          const float bv = (col < hid && h + kq < hid) ? wh[(size_t)col * hid + h + kq] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rows[li * hs + h + kq], bv, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // lane holds D[4 kq + r][li]
+        const int g = 4 * kq + r;
+        if (g < n && col < hid) {
+          const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
+          put(sid, col, acc[r]);
+        }
+      }
+    }
+  }
+}
+
 template <int HC>  // components per lane: hid <= 64 * HC
 __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat, const float *__restrict__ label_x,
                                                                  const float *__restrict__ wh,
@@ -77,7 +184,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   float *u_w = ws + ((size_t)lat.n_lattices + b) * lat.max_rows * hid;
   float *bh_out = beta_hat + (size_t)m.row_off * hid;
   auto bh_row = [&](int r) { return r < m.n_rows ? bh_out + (size_t)r * hid : bh_w + (size_t)r * hid; };
-  const int F = m.bwd_u, U = fmt_u(F), ST = fmt_words(F);
+  const int F = m.bwd_u, U = fmt_u(F);
   const uint32_t *prog = lat.bwd_stream + m.bwd_off;
   const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
@@ -100,29 +207,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   for (int i = tid; i < kNeuRows * hs; i += kNeuThreads) bh_s[i] = 0.0f;
   __syncthreads();
 
-  // The last wave stages tile T+1 (control words, records as 32-bit words, slot -> arc map, list
-  // of group leaders) while the others run phase A of tile T: its loads miss to HBM, and a wave's
-  // loads complete in order, so they must not sit in front of a computing wave's L2 hits.
-  auto stage_tile = [&](int T, uint32_t *st) {
-    uint32_t *ctl = st, *rec = st + 64;
-    int *cas = (int *)(st + 320), *lead = (int *)(st + 576), *nlead = (int *)(st + 640);
-    uint32_t c;
-    if (F == 8) {
-      const uint4 x = *reinterpret_cast<const uint4 *>(prog + (size_t)T * ST + lane * 4);
-      c = x.x;
-      const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rec[lane * 4 + j] = ((r[j] & 0x1fffu) << 3) | (((r[j] >> 13) & 0x7ffu) << 16);
-    } else {
-      c = prog[(size_t)T * ST + lane];
-      for (int j = 0; j < U; ++j) rec[lane + 64 * j] = prog[(size_t)T * ST + 64 + lane + 64 * j];
-    }
-    for (int j = 0; j < U; ++j) cas[lane + 64 * j] = perm[(size_t)T * 64 * U + lane + 64 * j];
-    ctl[lane] = c;
-    const uint64_t leaders = __builtin_amdgcn_ballot_w64((c >> 31) != 0);
-    if (c >> 31) lead[__builtin_popcountll(leaders & ((1ull << lane) - 1))] = lane;
-    if (lane == 0) nlead[0] = __builtin_popcountll(leaders);
-  };
+  auto stage_tile = [&](int T, uint32_t *st) { neu_stage_tile(prog, perm, F, T, st, lane); };
   if (wv == kNeuWaves - 1 && m.bwd_tiles > 0) stage_tile(0, stage_s);
   __syncthreads();
 
@@ -248,76 +333,239 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
     }
     __syncthreads();
 
-    // ---- B: u = Wh . beta_hat for the states this tile wrote, 16 of them per pass over Wh:
-    // D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32, one block of
-    // 16 columns per wave.  A comes from the LDS rows phase A filled, B straight from Wh (L2).
-    for (int g0 = 0; g0 < n_lead; g0 += 16) {
-      const int n = min(16, n_lead - g0);
-      const float *rows = bh_s + (size_t)g0 * hs;
-      if (g0 + 16 > kNeuRows) {  // more groups in the tile than LDS rows: fetch theirs from the workspace
-        __syncthreads();
-        for (int i = tid; i < n * hid; i += kNeuThreads) {
-          const int g = i / hid, h = i - g * hid;
-          const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
-          bh_s[g * hs + h] = bh_row(sid)[h];
-        }
-        __syncthreads();
-        rows = bh_s;
-      }
-      const int li = lane & 15, kq = lane >> 4;
-      for (int ct = wv; ct * 16 < hid; ct += kNeuWaves) {
-        const int col = ct * 16 + li;
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        if ((hid & 15) == 0) {
-          const float *bp = wh + (size_t)col * hid + 4 * kq;
-          const float *ap = rows + li * hs + 4 * kq;
-          int h = 0;
-          for (; h + 64 <= hid; h += 64) {  // four 16-byte loads of Wh in flight per lane
-            float4 bq[4], aq[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) bq[d] = *reinterpret_cast<const float4 *>(bp + h + 16 * d);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) aq[d] = *reinterpret_cast<const float4 *>(ap + h + 16 * d);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].x, bq[d].x, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].y, bq[d].y, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].z, bq[d].z, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[d].w, bq[d].w, acc, 0, 0, 0);
-            }
-          }
-          for (; h < hid; h += 16) {
-            const float4 bq = *reinterpret_cast<const float4 *>(bp + h);
-            const float4 aq = *reinterpret_cast<const float4 *>(ap + h);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq.w, acc, 0, 0, 0);
-          }
-        } else {
-          for (int h = 0; h < hid; h += 4) {  // the LDS rows are zero beyond hid
-            const float bv = (col < hid && h + kq < hid) ? wh[(size_t)col * hid + h + kq] : 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rows[li * hs + h + kq], bv, acc, 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {  // lane holds D[4 kq + r][li]
-          const int g = 4 * kq + r;
-          if (g < n && col < hid) {
-            const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
-            if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = acc[r];
-          }
-        }
-      }
-    }
+    // ---- B: u = Wh . beta_hat for the states this tile wrote (real rows only)
+    neu_phase_b(bh_s, hs, n_lead, wh, hid, ctl_s, lead_s, tid, wv, lane,
+                [&](int sid) { return (const float *)bh_row(sid); },
+                [&](int sid, int col, float v) { if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = v; });
     __threadfence_block();
     __syncthreads();
   }
 
   // ---- outputs: log beta; beta_hat is in place (rows the program never wrote: -inf, 0)
-  for (int r = tid; r < m.n_rows; r += kNeuThreads) log_beta[m.row_off + r] = me_log32(bme[r]);
+  float2 *bme_w = reinterpret_cast<float2 *>(ws + 2 * (size_t)lat.n_lattices * lat.max_rows * hid) + (size_t)b * lat.max_rows;
+  for (int r = tid; r < m.n_rows; r += kNeuThreads) {
+    log_beta[m.row_off + r] = me_log32(bme[r]);
+    bme_w[r] = bme[r];  // (mantissa, exponent) pairs for nfst_backward_neural_grad
+  }
   for (int r = wv; r < m.n_rows; r += kNeuWaves)
     if (!(bme[r].x > 0.0f))
       for (int h = lane; h < hid; h += 64) bh_out[(size_t)r * hid + h] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient of the neuralised beta sweep (tune_proposal differentiates log q through compute_beta,
+// /root/reference/src/modules/lightning.py:339-406; parameters scorers.py:954-970).
+// With z_a = W . t_a (+ arc_w) + log beta(d), p_a = exp(z_a - log beta(s)) and
+// lambda(s) = dL/d log beta(s), eta(s) = dL/d beta_hat(s), for an arc a = (s -l-> d):
+//     delta_a = p_a (lambda(s) + eta(s) . (t_a - beta_hat(s)))         = dL/dz_a
+//     lambda(d) = g(d) + sum_{a into d} delta_a
+//     tau_a = delta_a W + p_a eta(s),   rho_a = tau_a (1 - t_a^2)        = dL/d(x[l] + u(d))
+//     gamma(d) = sum_{a into d} rho_a,   eta(d) = Wh^T gamma(d) (+ g_beta_hat(d))
+//     dL/dx[l] += rho_a,   dL/dW += delta_a t_a,   dL/dWh = sum_d gamma(d) beta_hat(d)^T (host GEMM)
+// lambda and gamma of a state are sums over its INCOMING arcs and need lambda, eta of the arcs'
+// sources: exactly the alpha tile program (groups by destination, levels by depth), whose carry
+// records and scratch rows add partial sums.  t_a is recomputed from u(d), which the forward pass
+// left in its workspace together with beta as (mantissa, exponent) pairs -- p_a is a ratio of such
+// pairs, no float32 log beta in it.  Same phases as the forward kernel: A one wave per group, lanes
+// over H; B eta = Wh^T gamma on float32 MFMA for the states the tile finished.
+struct NeuGradLds {
+  int rows, hid;
+  __host__ __device__ NeuGradLds(int r, int h) : rows(r), hid(h) {}
+  // float2 beta[rows] | float lambda[rows] | two staged tiles | float gamma[32][row_stride]
+  __host__ __device__ int64_t bytes() const {
+    return (int64_t)rows * 12 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * NeuLds::row_stride(hid) * 4 + 16;
+  }
+};
+
+template <int HC>
+__global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
+    nfst_batch lat, const float *__restrict__ label_x, const float *__restrict__ whT, const float *__restrict__ wvec, int hid,
+    const float *__restrict__ beta_hat, const float *__restrict__ ws_fwd, const float *__restrict__ g_logbeta,
+    const float *__restrict__ g_betahat, float *gamma, float *grad_label_x, float *grad_w, float *ws) {
+  extern __shared__ float2 lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Meta m = load_meta(lat.meta, b);
+  float2 *bme = lds;
+  float *lam = (float *)(bme + lat.max_rows);
+  uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
+  float *gs = (float *)(stage_s + 2 * kNeuStageWords);
+  const size_t plane = (size_t)lat.n_lattices * lat.max_rows * hid;
+  const float *u_w = ws_fwd + plane + (size_t)b * lat.max_rows * hid;  // u = Wh . beta_hat of the real rows
+  const float2 *bme_w = reinterpret_cast<const float2 *>(ws_fwd + 2 * plane) + (size_t)b * lat.max_rows;
+  float *gam_w = ws + (size_t)b * lat.max_rows * hid;          // gamma of scratch rows
+  float *eta_w = ws + plane + (size_t)b * lat.max_rows * hid;  // eta of real rows
+  float *gam_out = gamma + (size_t)m.row_off * hid;
+  const float *bh_in = beta_hat + (size_t)m.row_off * hid;
+  auto gam_row = [&](int r) { return r < m.n_rows ? gam_out + (size_t)r * hid : gam_w + (size_t)r * hid; };
+  const int F = m.fwd_u, U = fmt_u(F);
+  const uint32_t *prog = lat.fwd_stream + m.fwd_off;
+  const int32_t *perm = lat.fwd_perm + m.fwd_slot_off;
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  const int V = lat.vocab;
+
+  for (int i = tid; i < lat.max_rows; i += kNeuThreads) {
+    bme[i] = i < m.n_rows ? bme_w[i] : make_float2(0.0f, __int_as_float(kEZero));
+    lam[i] = 0.0f;
+  }
+  // the start state has no incoming arc: lambda(0) = g(0), eta(0) = g_beta_hat(0)
+  for (int i = tid; i < hid; i += kNeuThreads) eta_w[i] = g_betahat ? g_betahat[(size_t)m.row_off * hid + i] : 0.0f;
+  float wl[HC], gw[HC];
+#pragma unroll
+  for (int c = 0; c < HC; ++c) {
+    wl[c] = (c * 64 + lane < hid) ? wvec[c * 64 + lane] : 0.0f;
+    gw[c] = 0.0f;
+  }
+  const int hs = NeuLds::row_stride(hid);
+  for (int i = tid; i < kNeuRows * hs; i += kNeuThreads) gs[i] = 0.0f;
+  __syncthreads();
+  if (tid == 0) lam[0] = g_logbeta[m.row_off];
+  if (wv == kNeuWaves - 1 && m.fwd_tiles > 0) neu_stage_tile(prog, perm, F, 0, stage_s, lane);
+  __threadfence_block();
+  __syncthreads();
+
+  for (int T = 0; T < m.fwd_tiles; ++T) {
+    uint32_t *st = stage_s + (T & 1) * kNeuStageWords;
+    const uint32_t *ctl_s = st, *rec_s = st + 64;
+    const int *cas_s = (const int *)(st + 320), *lead_s = (const int *)(st + 576), *nlead_s = (const int *)(st + 640);
+    if (wv == kNeuWaves - 1 && T + 1 < m.fwd_tiles) neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuStageWords, lane);
+    const int n_lead = nlead_s[0];
+
+    // ---- A: one wave per group (a destination state, or a scratch row holding a partial sum)
+    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+      const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
+      const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
+      const bool continuation = (c0 >> 30) & 1u;
+      float lacc = 0.0f, gacc[HC], ud[HC];
+#pragma unroll
+      for (int c = 0; c < HC; ++c) { gacc[c] = 0.0f; ud[c] = 0.0f; }
+      float2 bd = make_float2(0.0f, __int_as_float(kEZero));  // beta of the destination state
+      bool have_d = false;
+      for (int q0 = 0; q0 < n_rec; q0 += 64) {
+        uint32_t rc_l = 0;
+        int ca_l = -1;
+        if (q0 + lane < n_rec) { rc_l = rec_s[l0 * U + q0 + lane]; ca_l = cas_s[l0 * U + q0 + lane]; }
+        const uint64_t real = __builtin_amdgcn_ballot_w64(ca_l >= 0);
+        uint64_t todo = real | __builtin_amdgcn_ballot_w64(ca_l < 0 && (int)(rc_l >> 16) == V + 1);
+        if (real && !have_d) {  // every real record of a group enters the same state: the row of u and beta
+          const int a0 = __builtin_amdgcn_readlane(ca_l, __builtin_ctzll(real));
+          const int d = lat.arc_dst[a0];
+          bd = bme[d];
+#pragma unroll
+          for (int c = 0; c < HC; ++c) ud[c] = u_w[(size_t)d * hid + min(c * 64 + lane, hid - 1)];
+          have_d = true;
+        }
+        // one record per lane: source row, its beta and lambda, the table weight
+        const int src_l = (int)((rc_l & 0xffffu) >> 3);
+        const float x_l = (arc_w && ca_l >= 0) ? arc_w[ca_l] : 0.0f;
+        const float2 bs_l = bme[src_l];
+        const float lam_l = lam[src_l];
+        // records one after the other, the operand rows of the next one in flight meanwhile
+        struct Ops { float a[HC], bh[HC], et[HC]; int p, ca, lab, src; };
+        auto issue = [&](int p) {
+          Ops o;
+          o.p = p;
+          const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)rc_l, p);
+          o.ca = __builtin_amdgcn_readlane(ca_l, p);
+          o.src = (int)((rc & 0xffffu) >> 3);
+          o.lab = (int)(rc >> 16);
+          if (o.ca >= 0) {
+            const float *pa = label_x + (size_t)o.lab * hid, *pb = bh_in + (size_t)o.src * hid, *pe = eta_w + (size_t)o.src * hid;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+              const int h = min(c * 64 + lane, hid - 1);
+              o.a[c] = pa[h];
+              o.bh[c] = pb[h];
+              o.et[c] = neu_load_fresh(pe + h);
+            }
+          } else {  // a partial sum: gamma of the operand row
+            const float *pg = gam_row(o.src);
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+              o.a[c] = neu_load_fresh(pg + min(c * 64 + lane, hid - 1));
+              o.bh[c] = 0.0f;
+              o.et[c] = 0.0f;
+            }
+          }
+          return o;
+        };
+        Ops cur;
+        if (todo) { cur = issue(__builtin_ctzll(todo)); todo &= todo - 1; }
+        else continue;
+        constexpr bool kPrefetch = HC <= 4;  // (with 8 components per lane two records' rows do not fit the registers)
+        for (;;) {
+          const bool more = todo != 0;
+          Ops nxt;
+          if (kPrefetch && more) { nxt = issue(__builtin_ctzll(todo)); todo &= todo - 1; }
+          if (cur.ca >= 0) {
+            float t[HC], p1 = 0.0f, p2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+              const bool in = c * 64 + lane < hid;
+              t[c] = in ? neu_tanh(cur.a[c] + ud[c]) : 0.0f;
+              p1 = fmaf(wl[c], t[c], p1);
+              p2 = fmaf(in ? cur.et[c] : 0.0f, t[c] - (in ? cur.bh[c] : 0.0f), p2);
+            }
+            const float sc = wave_sum(p1), dot = wave_sum(p2);
+            // wave-uniform: p = exp(sc + table weight) beta(d) / beta(s)
+            const float xs = read_lane_f(x_l, cur.p), lam_s = read_lane_f(lam_l, cur.p);
+            const float bsm = read_lane_f(bs_l.x, cur.p);
+            const int bse = __builtin_amdgcn_readlane(__float_as_int(bs_l.y), cur.p);
+            const ME w = exp_split(sc + xs);
+            const float pm = bsm > 0.0f ? w.m * bd.x / bsm : 0.0f;
+            const int pe = w.e + __float_as_int(bd.y) - bse;
+            const float pa = ldexpf(pm, max(min(pe, 64), -300));
+            const float delta = pa * (lam_s + dot);
+            lacc += delta;
+            float *gx = grad_label_x + (size_t)cur.lab * hid;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+              const int h = c * 64 + lane;
+              if (h < hid) {
+                const float tau = fmaf(delta, wl[c], pa * cur.et[c]);
+                const float rho = tau * fmaf(-t[c], t[c], 1.0f);
+                gacc[c] += rho;
+                gw[c] = fmaf(delta, t[c], gw[c]);
+                unsafeAtomicAdd(gx + h, rho);
+              }
+            }
+          } else {
+            lacc += read_lane_f(lam_l, cur.p);
+#pragma unroll
+            for (int c = 0; c < HC; ++c) gacc[c] += (c * 64 + lane < hid) ? cur.a[c] : 0.0f;
+          }
+          if (!more) break;
+          if (kPrefetch) cur = nxt;
+          else { cur = issue(__builtin_ctzll(todo)); todo &= todo - 1; }
+        }
+      }
+      if (sid < m.n_rows && !continuation) lacc += g_logbeta[m.row_off + sid];
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        const int h = c * 64 + lane;
+        if (h < hid) {
+          gam_row(sid)[h] = gacc[c];
+          if (i < kNeuRows) gs[i * hs + h] = gacc[c];
+        }
+      }
+      if (lane == 0) lam[sid] = lacc;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- B: eta = Wh^T gamma (+ the caller's gradient w.r.t. beta_hat) for the real rows
+    neu_phase_b(gs, hs, n_lead, whT, hid, ctl_s, lead_s, tid, wv, lane,
+                [&](int sid) { return (const float *)gam_row(sid); },
+                [&](int sid, int col, float v) {
+                  if (sid < m.n_rows)
+                    eta_w[(size_t)sid * hid + col] = v + (g_betahat ? g_betahat[((size_t)m.row_off + sid) * hid + col] : 0.0f);
+                });
+    __threadfence_block();
+    __syncthreads();
+  }
+  // dL/dW: one atomic add per wave and component
+#pragma unroll
+  for (int c = 0; c < HC; ++c)
+    if (c * 64 + lane < hid && gw[c] != 0.0f) unsafeAtomicAdd(grad_w + c * 64 + lane, gw[c]);
 }

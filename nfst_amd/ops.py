@@ -401,19 +401,60 @@ class NeuralBeta(NamedTuple):
     beta_hat: torch.Tensor   # [total_rows, H]
 
 
+class _NeuralBeta(torch.autograd.Function):
+    """nfst_backward_neural with nfst_backward_neural_grad behind it: differentiable in label_x
+    ([V, H] = emb Wx^T + bias, made by torch ops, so Wx, bias and the embeddings get their gradients
+    through it), Wh and w."""
+
+    @staticmethod
+    def forward(ctx, lat, label_x, wh, w):
+        f32 = dict(device=lat.device, dtype=torch.float32)
+        H = w.shape[0]
+        s = lat.c_struct()
+        ws = torch.empty(int(lib.nfst_neural_ws_floats(C.byref(s), H)), **f32)
+        log_beta = torch.empty(lat.total_rows, **f32)
+        beta_hat = torch.empty(lat.total_rows, H, **f32)
+        check(lib.nfst_backward_neural(C.byref(s), label_x.data_ptr(), wh.data_ptr(), w.data_ptr(), H, log_beta.data_ptr(),
+                                       beta_hat.data_ptr(), ws.data_ptr(), _stream()), "nfst_backward_neural")
+        ctx.lat = lat
+        ctx.save_for_backward(label_x, wh, w, beta_hat, ws)
+        return log_beta, beta_hat
+
+    @staticmethod
+    def backward(ctx, g_log_beta, g_beta_hat):
+        lat = ctx.lat
+        label_x, wh, w, beta_hat, ws_fwd = ctx.saved_tensors
+        f32 = dict(device=lat.device, dtype=torch.float32)
+        H = w.shape[0]
+        s = lat.c_struct()
+        g_lb = (torch.zeros(lat.total_rows, **f32) if g_log_beta is None else g_log_beta.to(**f32)).contiguous()
+        # rows the sweep never reached carry -inf and no gradient
+        g_lb = torch.where(torch.isfinite(g_lb), g_lb, torch.zeros_like(g_lb))
+        g_bh = None if g_beta_hat is None else g_beta_hat.to(**f32).contiguous()
+        gamma = torch.zeros(lat.total_rows, H, **f32)
+        g_x = torch.zeros_like(label_x)
+        g_w = torch.zeros(H, **f32)
+        ws = torch.empty(int(lib.nfst_neural_grad_ws_floats(C.byref(s), H)), **f32)
+        wh_t = wh.t().contiguous()
+        check(lib.nfst_backward_neural_grad(C.byref(s), label_x.data_ptr(), wh_t.data_ptr(), w.data_ptr(), H,
+                                            beta_hat.data_ptr(), ws_fwd.data_ptr(), g_lb.data_ptr(),
+                                            0 if g_bh is None else g_bh.data_ptr(), gamma.data_ptr(), g_x.data_ptr(),
+                                            g_w.data_ptr(), ws.data_ptr(), _stream()), "nfst_backward_neural_grad")
+        # dL/dWh[i, j] = sum over states of gamma(s)[i] beta_hat(s)[j]: one library GEMM
+        g_wh = gamma.t() @ beta_hat
+        return None, g_x, g_wh, g_w
+
+
 def backward_neural(lat: LatticeBatch, emb: torch.Tensor, Wx: torch.Tensor, Wh: torch.Tensor, W: torch.Tensor,
                     bias: torch.Tensor) -> NeuralBeta:
     """``FSAGRUScorer.compute_beta_per_sample`` / ``compute_beta_parallel`` with their Tree-LSTM-style
     messages (scorers.py:692-751, 753-856), parameters named as there: ``emb`` [V, H] mark embeddings,
     ``Wx``, ``Wh`` [H, H], ``W`` [1, H] or [H], ``bias`` [H].  The per-label part ``Wx e(l) + bias`` is
     one [V, H] x [H, H] product made here (a plain library GEMM); everything that depends on the
-    lattice runs in the kernel."""
+    lattice runs in the kernel.  Differentiable in all five parameters (the reference's
+    ``tune_proposal`` trains them through ``compute_beta``, lightning.py:339-406): the gradient is
+    ``nfst_backward_neural_grad`` plus two library GEMMs."""
     _need_gpu(lat)
-    if torch.is_grad_enabled() and any(isinstance(p, torch.Tensor) and p.requires_grad for p in (emb, Wx, Wh, W, bias)):
-        # forward only: the reference differentiates log q through compute_beta() (tune_proposal,
-        # lightning.py:339-406); no backward kernel exists yet, and a silent zero gradient would be worse
-        raise RuntimeError("nfst_amd: backward_neural has no backward pass yet (forward only); call it under "
-                           "torch.no_grad() or detach the parameters")
     f32 = dict(device=lat.device, dtype=torch.float32)
     emb, Wx, Wh, bias = emb.to(**f32), Wx.to(**f32), Wh.to(**f32), bias.to(**f32)
     w = W.to(**f32).reshape(-1).contiguous()
@@ -421,14 +462,7 @@ def backward_neural(lat: LatticeBatch, emb: torch.Tensor, Wx: torch.Tensor, Wh: 
     if emb.shape != (lat.vocab, H) or Wx.shape != (H, H) or Wh.shape != (H, H) or bias.shape != (H,):
         raise ValueError("emb must be [V, H], Wx and Wh [H, H], W [H] and bias [H]")
     label_x = torch.addmm(bias, emb, Wx.t()).contiguous()
-    wh = Wh.contiguous()
-    s = lat.c_struct()
-    ws = torch.empty(int(lib.nfst_neural_ws_floats(C.byref(s), H)), **f32)
-    log_beta = torch.empty(lat.total_rows, **f32)
-    beta_hat = torch.empty(lat.total_rows, H, **f32)
-    check(lib.nfst_backward_neural(C.byref(s), label_x.data_ptr(), wh.data_ptr(), w.data_ptr(), H, log_beta.data_ptr(),
-                                   beta_hat.data_ptr(), ws.data_ptr(), _stream()), "nfst_backward_neural")
-    return NeuralBeta(log_beta, beta_hat)
+    return NeuralBeta(*_NeuralBeta.apply(lat, label_x, Wh.contiguous(), w))
 
 
 def gather_label_scores(lat: LatticeBatch, theta, arc_scores=None) -> torch.Tensor:

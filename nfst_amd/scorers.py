@@ -123,8 +123,7 @@ class NeuralBetaScorer(LatticeScorer):
     def compute_beta_hat(self):
         """``(log beta [B*k, S+1], beta_hat [B*k, S+1, H])``."""
         lat = self._lat()
-        with torch.no_grad():
-            r = ops.backward_neural(lat, self.embeddings.weight, self.Wx, self.Wh, self.W, self.beta_bias)
+        r = ops.backward_neural(lat, self.embeddings.weight, self.Wx, self.Wh, self.W, self.beta_bias)
         return (lat.rows_view(r.log_beta).repeat_interleave(self.k, dim=0),
                 lat.rows_view(r.beta_hat).repeat_interleave(self.k, dim=0))
 

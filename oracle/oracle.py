@@ -255,6 +255,66 @@ def beta_neural(n_rows: int, src, label, dst, emb, Wx, Wh, W, bias, arc_w=None):
     return logb, bhat
 
 
+def beta_neural_grad(n_rows: int, src, label, dst, emb, Wx, Wh, W, bias, coef, arc_w=None, coef_hat=None):
+    """Gradients of L = sum_s coef[s] log beta(s) (+ sum coef_hat[s] . beta_hat(s)) through the
+    recurrence of ``beta_neural`` (scorers.py:692-751) with respect to emb, Wx, Wh, W, bias:
+    torch.autograd in float64 over an out-of-place restatement (the reference's own functions update
+    tensors in place and autograd refuses them; the forward values of this restatement are pinned by
+    beta_neural.npz, its derivatives by the central differences of the reference's forward pass in
+    beta_neural_grad.npz).  States with coef != 0 must reach the sink.  Returns (loss, log_beta,
+    beta_hat, dict of gradients) as numpy float64."""
+    import torch
+    f64 = torch.float64
+    src = np.asarray(src, np.int64); label = np.asarray(label, np.int64); dst = np.asarray(dst, np.int64)
+    keep = src != dst
+    aw = np.zeros(src.shape[0]) if arc_w is None else np.asarray(arc_w, np.float64)
+    src, label, dst, aw = src[keep], label[keep], dst[keep], aw[keep]
+    P = {k: torch.tensor(np.asarray(v, np.float64), dtype=f64, requires_grad=True)
+         for k, v in dict(emb=emb, Wx=Wx, Wh=Wh, W=np.asarray(W).reshape(-1), bias=bias).items()}
+    H = P["emb"].shape[1]
+    x = P["emb"] @ P["Wx"].T + P["bias"]
+    out = [[] for _ in range(n_rows)]
+    into = [[] for _ in range(n_rows)]
+    pending = np.zeros(n_rows, np.int64)
+    for a in range(src.shape[0]):
+        out[src[a]].append(a); into[dst[a]].append(a); pending[src[a]] += 1
+    sinks = [s for s in range(n_rows) if pending[s] == 0 and into[s]]
+    if len(sinks) != 1:
+        raise OracleError("not exactly one sink")
+    logb = [None] * n_rows
+    bhat = [None] * n_rows
+    logb[sinks[0]] = torch.zeros((), dtype=f64)
+    bhat[sinks[0]] = torch.zeros(H, dtype=f64)
+    ready = [sinks[0]]
+    aw_t = torch.tensor(aw, dtype=f64)
+    while ready:
+        s2 = ready.pop()
+        for a in into[s2]:
+            s = src[a]
+            pending[s] -= 1
+            if pending[s] == 0:
+                arcs = out[s]
+                bh = torch.stack([bhat[dst[i]] for i in arcs])
+                lb = torch.stack([logb[dst[i]] for i in arcs])
+                t = torch.tanh(x[torch.as_tensor(label[arcs])] + bh @ P["Wh"].T)
+                lm = t @ P["W"] + aw_t[torch.as_tensor(arcs)] + lb
+                logb[s] = torch.logsumexp(lm, 0)
+                bhat[s] = torch.softmax(lm, 0) @ t
+                ready.append(s)
+    coef = np.asarray(coef, np.float64)
+    loss = torch.zeros((), dtype=f64)
+    for s in range(n_rows):
+        if coef[s] != 0.0:
+            loss = loss + coef[s] * logb[s]
+        if coef_hat is not None and logb[s] is not None:
+            loss = loss + (torch.tensor(np.asarray(coef_hat[s], np.float64)) * bhat[s]).sum()
+    loss.backward()
+    lb_np = np.array([float(v.detach()) if v is not None else -np.inf for v in logb])
+    bh_np = np.stack([v.detach().numpy() if v is not None else np.zeros(H) for v in bhat])
+    grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in P.items()}
+    return float(loss.detach()), lb_np, bh_np, grads
+
+
 # --------------------------------------------------------------------------- estimator side
 def stripping_pad(seqs: np.ndarray, pad: int) -> np.ndarray:
     """Sampler.stripping_pad (samplers.py:162-180): drop marks equal to 0, left-align."""

@@ -15,6 +15,10 @@ What is pinned (reference file:line):
                  (scorers.py:692-751, 753-856) with Wh = 0, i.e. arc weight
                  exp(theta[label]);  includes the parallel-arc quirk fixture.
   beta_neural.npz  the same two functions with Wh != 0 (Tree-LSTM-style messages).
+  beta_neural_grad.npz  directional derivatives of compute_beta_per_sample w.r.t. Wh, Wx, W,
+                 beta_bias and the embeddings (central differences of the reference's forward pass in
+                 float64 -- torch.autograd refuses the reference's in-place updates; tune_proposal,
+                 lightning.py:339-406).
   gather.npz     set_masks/set_k (877-918), update_fsa_state (683-690),
                  mask_out_invalid (1037-1054 on top of 314-338) on a collated,
                  pad-padded batch (dataset_reader.py:175-186).
@@ -217,6 +221,71 @@ def make_beta_neural():
             bias=sc.beta_bias.detach().numpy().astype(np.float32), n_rows=np.int64(lat.n_rows),
             src=lat.src, label=lat.label, dst=lat.dst, transition=tr).items()})
     save("beta_neural.npz", **out)
+
+
+def make_beta_neural_grad():
+    """Derivatives of compute_beta_per_sample (scorers.py:692-751) with respect to the parameters
+    tune_proposal trains through compute_beta (lightning.py:339-406; scorers.py:954-970).  The
+    reference's two beta functions update their tensors in place (scorers.py:744-747, 806-817) and
+    torch.autograd refuses to differentiate either ("modified by an inplace operation"), so the
+    fixture holds DIRECTIONAL derivatives of the reference's own forward pass instead: central
+    differences in float64 of L = sum_s coef[s] log beta(s) (states reachable from state 0) along
+    random directions in every parameter."""
+    cases = {
+        "grad_layered12_h8": (synth.layered_lattice(41, n_states=12, avg_degree=3.0, vocab=29, width=3, span=2), 8),
+        "grad_layered40_h16": (synth.layered_lattice(42, n_states=40, avg_degree=4.0, vocab=29, width=4, span=3), 16),
+        "grad_layered60_h64": (synth.layered_lattice(43, n_states=60, avg_degree=5.0, vocab=29, width=5, span=3), 64),
+        "grad_edit_h8": (synth.edit_lattice([10, 11, 12], [20, 21, 22, 23], vocab=29, seed=7), 8),
+    }
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    try:
+        for name, (lat, H) in cases.items():
+            torch.manual_seed(len(name) + H)
+            sc = FSAGRUScorer(hid_dim=H, vocab_size=lat.vocab, pad=PAD, bos=BOS, eos=EOS, use_beta=True, max_length=64)
+            sc.eval()
+            with torch.no_grad():
+                sc.beta_bias.copy_(0.3 * torch.randn(H))
+                sc.Wh.mul_(2.0)
+                for p in sc.parameters():  # parameters that are exactly representable in float32
+                    p.copy_(p.float().double())
+            _, tr = lat.dense()
+            tr_t = torch.from_numpy(tr)
+            reach = np.zeros(lat.n_rows, bool)
+            reach[0] = True
+            for _ in range(lat.n_rows):
+                reach[lat.dst[reach[lat.src]]] = True
+            rng = np.random.default_rng(len(name))
+            coef = np.where(reach, rng.normal(size=lat.n_rows), 0.0).astype(np.float32)
+            coef_t, reach_t = torch.from_numpy(coef.astype(np.float64)), torch.from_numpy(reach)
+
+            def loss():
+                with torch.no_grad():
+                    beta = sc.compute_beta_per_sample(tr_t)[: lat.n_rows]
+                return float((coef_t[reach_t] * torch.log(beta[reach_t])).sum())
+
+            params = dict(emb=sc.embeddings.weight, Wx=sc.Wx, Wh=sc.Wh, W=sc.W, bias=sc.beta_bias)
+            rec = dict(coef=coef, loss=np.float64(loss()), n_rows=np.int64(lat.n_rows), src=lat.src, label=lat.label, dst=lat.dst)
+            for k, p in params.items():
+                rec[k] = p.detach().numpy().astype(np.float32)
+            eps = 1e-5
+            for k, p in params.items():
+                dirs, dds = [], []
+                for _ in range(3):
+                    d = torch.from_numpy(rng.normal(size=tuple(p.shape)))
+                    with torch.no_grad():
+                        p.add_(eps * d); up = loss()
+                        p.sub_(2 * eps * d); dn = loss()
+                        p.add_(eps * d)
+                    dirs.append(d.numpy().astype(np.float32))
+                    dds.append((up - dn) / (2 * eps))
+                # (the stored direction is the float32 rounding of the one used: 6e-8 relative)
+                rec[f"dir_{k}"] = np.stack(dirs)
+                rec[f"dd_{k}"] = np.asarray(dds, np.float64)
+            out.update({f"{name}_{k}": v for k, v in rec.items()})
+    finally:
+        torch.set_default_dtype(torch.float32)
+    save("beta_neural_grad.npz", **out)
 
 
 def make_gather():
@@ -511,7 +580,7 @@ def make_strip():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py make_beta_neural`; nothing = all
-    for fn in (make_beta, make_beta_neural, make_gather, make_sampler_and_iwae, make_evalseq, make_evalseq_grad, make_gpt2,
+    for fn in (make_beta, make_beta_neural, make_beta_neural_grad, make_gather, make_sampler_and_iwae, make_evalseq, make_evalseq_grad, make_gpt2,
                make_strip, make_sampler_beta):
         if not only or fn.__name__ in only:
             fn()

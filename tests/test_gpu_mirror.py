@@ -154,10 +154,12 @@ def test_neural_beta_scorer_matches_reference(dev, golden_dir):
     np.testing.assert_allclose(beta[0], c["beta_per_sample"], rtol=5e-5)
     _, bhat = sc.compute_beta_hat()
     assert bhat.shape == (3, tr.shape[0], H) and float(bhat.abs().max()) <= 1.0
-    # forward only: asking for gradients of the parameters is refused loudly, never answered with zeros
-    from nfst_amd import ops
-    with pytest.raises(RuntimeError, match="forward only"):
-        ops.backward_neural(sc._lat(), sc.embeddings.weight, sc.Wx, sc.Wh, sc.W, sc.beta_bias)
+    # trainable as in tune_proposal (lightning.py:339-406): the scorer's parameters get gradients through
+    # compute_beta (they match float64 autograd over the restatement in test_gpu_parity.py)
+    lb = sc.compute_log_beta()
+    lb[0][torch.isfinite(lb[0])].sum().backward()
+    for p in (sc.Wh, sc.Wx, sc.W, sc.beta_bias, sc.embeddings.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
 
 
 def test_proposal_sampler_replays_reference_sampler(dev, golden_dir):

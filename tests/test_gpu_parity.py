@@ -938,3 +938,102 @@ def test_beta_neural_weighted_tables_and_zero_wh(dev):
         r0 = int(lat.row_off[b])
         cmp_rows(r.log_beta.cpu().numpy()[r0:r0 + l.n_rows], logb, tol=3e-5)
         assert np.max(np.abs(r.beta_hat.cpu().numpy()[r0:r0 + l.n_rows] - bhat)) <= 3e-5
+
+
+# ----------------------------------------------------------------------------- gradient of the neuralised beta
+NEURAL_GRAD = ["grad_layered12_h8", "grad_layered40_h16", "grad_layered60_h64", "grad_edit_h8"]
+PARAMS = ("emb", "Wx", "Wh", "W", "bias")
+
+
+def _neural_grads(lat, p, coef_rows, coef_hat=None):
+    """loss = sum coef . log beta (+ sum coef_hat . beta_hat) through ops.backward_neural; returns
+    (loss, NeuralBeta, {name: grad})."""
+    t = {k: torch.from_numpy(np.asarray(p[k], np.float32)).to(lat.device).requires_grad_(True) for k in PARAMS}
+    r = ops.backward_neural(lat, *(t[k] for k in PARAMS))
+    c = torch.from_numpy(np.asarray(coef_rows, np.float32)).to(lat.device)
+    loss = (c[c != 0] * r.log_beta[c != 0]).sum()
+    if coef_hat is not None:
+        loss = loss + (torch.from_numpy(np.asarray(coef_hat, np.float32)).to(lat.device) * r.beta_hat).sum()
+    loss.backward()
+    return float(loss.detach()), r, {k: t[k].grad.detach().cpu().numpy().astype(np.float64) for k in PARAMS}
+
+
+def _rel(got, ref):
+    return float(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30))
+
+
+@pytest.mark.parametrize("name", NEURAL_GRAD)
+def test_beta_neural_grad_matches_reference_differences(dev, golden_dir, name):
+    """d/d(Wh, Wx, W, beta_bias, embeddings) of sum coef . log beta (tune_proposal trains these through
+    compute_beta, lightning.py:339-406) against central differences of the REFERENCE's own forward pass
+    in float64 (torch.autograd refuses the reference's in-place updates) and against float64 autograd
+    over the restatement."""
+    with np.load(os.path.join(golden_dir, "beta_neural_grad.npz")) as g:
+        c = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+    n_rows = int(c["n_rows"])
+    lat = LatticeBatch.from_arcs([n_rows], [0, c["src"].shape[0]], c["src"], c["label"], c["dst"], c["emb"].shape[0], device=dev)
+    loss, _, got = _neural_grads(lat, c, c["coef"])
+    assert abs(loss - float(c["loss"])) <= 2e-5 * max(1.0, abs(float(c["loss"])))
+    for k in PARAMS:
+        scale = max(1.0, float(np.max(np.abs(c["dd_" + k]))))
+        for d, dd in zip(c["dir_" + k], c["dd_" + k]):
+            val = float((got[k].reshape(-1) * d.astype(np.float64).reshape(-1)).sum())
+            assert rec("neural_grad_vs_reference_fd", abs(val - dd) / scale) <= 1e-4, (k, val, dd)
+    _, _, _, ref = O.beta_neural_grad(n_rows, c["src"], c["label"], c["dst"], c["emb"], c["Wx"], c["Wh"], c["W"], c["bias"], c["coef"])
+    for k in PARAMS:
+        assert rec("neural_grad_rel", _rel(got[k].reshape(-1), ref[k].reshape(-1))) <= 1e-4, k
+
+
+@pytest.mark.parametrize("H", [8, 64, 100, 256, 512])
+def test_beta_neural_grad_against_autograd(dev, H):
+    """Mixed batch (weighted tables; a near-sequential, a layered and a wide lattice) under several
+    packings, with gradients entering through log beta AND beta_hat: float64 autograd over the
+    restatement, <= 1e-4 relative."""
+    V = 64
+    lats = [synth.layered_lattice(71, n_states=120, avg_degree=5.0, vocab=V, width=4, span=3, weighted=True),
+            synth.layered_lattice(72, n_states=40, avg_degree=3.0, vocab=V, width=1, span=2, weighted=True),
+            synth.layered_lattice(73, n_states=200, avg_degree=10.0, vocab=V, width=20, span=2, max_degree=30, weighted=True)]
+    p = _neural_params(H + 1, V, H, scale=2.0)
+    rng = np.random.default_rng(H)
+    coefs = [rng.normal(size=l.n_rows) for l in lats]
+    chats = [0.3 * rng.normal(size=(l.n_rows, H)) for l in lats]
+    ref = {k: 0.0 for k in PARAMS}
+    for l, c, ch in zip(lats, coefs, chats):
+        _, logb, _, g = O.beta_neural_grad(l.n_rows, l.src, l.label, l.dst, p["emb"], p["Wx"], p["Wh"], p["W"], p["bias"], c,
+                                           arc_w=l.weight, coef_hat=ch)
+        assert np.all(np.isfinite(logb[np.asarray(c) != 0]))
+        for k in PARAMS:
+            ref[k] = ref[k] + g[k].reshape(np.shape(p[k]))
+    all_opts = (dict(), dict(slots_per_lane=1), dict(slots_per_lane=2, group_mode=1), dict(slots_per_lane=4, no_compact=True),
+                dict(group_mode=2)) if H in (8, 256) else (dict(), dict(group_mode=1, slots_per_lane=1))
+    for opts in all_opts:
+        lat = LatticeBatch.from_synth(lats, device=dev, **opts)
+        rows = np.zeros(lat.total_rows)
+        hat = np.zeros((lat.total_rows, H))
+        for b, (l, c, ch) in enumerate(zip(lats, coefs, chats)):
+            r0 = int(lat.row_off[b])
+            rows[r0:r0 + l.n_rows] = c
+            hat[r0:r0 + l.n_rows] = ch
+        _, _, got = _neural_grads(lat, p, rows, hat)
+        for k in PARAMS:
+            assert rec(f"neural_grad_rel_H{H}", _rel(got[k], ref[k])) <= 1e-4, (H, opts, k)
+
+
+def test_beta_neural_grad_funnels(dev):
+    """Fan-in / fan-out of 200 arcs twice in a row (carry pieces, partial groups whose scratch rows are
+    rewritten at the next level), forward values and gradients."""
+    V, H = 256, 16
+    src = [0] + [1] * 200 + list(range(2, 202)) + [202] * 200 + list(range(203, 403)) + [403]
+    lab = [BOS] + list(range(3, 203)) + [5] * 200 + list(range(3, 203)) + [6] * 200 + [EOS]
+    dst = [1] + list(range(2, 202)) + [202] * 200 + list(range(203, 403)) + [403] * 200 + [404]
+    l = synth._finish(405, V, src, lab, dst)
+    p = _neural_params(9, V, H, scale=2.0)
+    coef = np.random.default_rng(3).normal(size=l.n_rows)
+    _, logb, bhat, ref = O.beta_neural_grad(l.n_rows, l.src, l.label, l.dst, p["emb"], p["Wx"], p["Wh"], p["W"], p["bias"], coef)
+    for opts in (dict(), dict(slots_per_lane=1), dict(group_mode=2), dict(slots_per_lane=2, group_mode=1)):
+        lat = LatticeBatch.from_synth([l], device=dev, **opts)
+        _, r, got = _neural_grads(lat, p, coef)
+        cmp_rows(r.log_beta.detach().cpu().numpy()[: l.n_rows], logb, tol=3e-5)
+        assert np.max(np.abs(r.beta_hat.detach().cpu().numpy()[: l.n_rows] - bhat)) <= 3e-5
+        for k in PARAMS:
+            assert rec("neural_grad_rel_funnels", _rel(got[k], ref[k].reshape(np.shape(p[k])))) <= 1e-4, (opts, k)

@@ -286,3 +286,25 @@ def test_gpt2_wrapper_arithmetic(golden_dir, V):
 def test_stripping_pad_fixture(golden_dir, pad):
     d = load(golden_dir, "strip")
     assert np.array_equal(O.stripping_pad(d[f"pad{pad}_in"], pad), d[f"pad{pad}_out"])
+
+
+NEURAL_GRAD = ["grad_layered12_h8", "grad_layered40_h16", "grad_layered60_h64", "grad_edit_h8"]
+
+
+def neural_grad_case(golden_dir, name):
+    with np.load(os.path.join(golden_dir, "beta_neural_grad.npz")) as g:
+        return {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+
+
+@pytest.mark.parametrize("name", NEURAL_GRAD)
+def test_beta_neural_grad_matches_reference_differences(golden_dir, name):
+    """The float64 autograd restatement against central differences of the REFERENCE's forward pass
+    (compute_beta_per_sample in float64; its in-place updates rule out torch.autograd on it)."""
+    c = neural_grad_case(golden_dir, name)
+    loss, _, _, g = O.beta_neural_grad(int(c["n_rows"]), c["src"], c["label"], c["dst"], c["emb"], c["Wx"], c["Wh"], c["W"],
+                                       c["bias"], c["coef"])
+    assert abs(loss - float(c["loss"])) <= 1e-9 * max(1.0, abs(loss))
+    for k in ("emb", "Wx", "Wh", "W", "bias"):
+        for d, dd in zip(c["dir_" + k], c["dd_" + k]):
+            got = float((g[k].reshape(-1) * d.astype(np.float64).reshape(-1)).sum())
+            assert abs(got - dd) <= 1e-6 * max(1.0, abs(dd)), (k, got, dd)
