@@ -226,9 +226,10 @@ class Stepper:
             self.out = ops.forward_backward(self.lat, self.theta, arc_scores=self.arc_scores, want_alpha_beta=True,
                                             want_posterior=True, out=self.out, **kw)
         elif self.mode == "fb_sweeps_only":
-            self.out = ops.forward_backward(self.lat, self.theta, want_alpha_beta=False, want_posterior=False, out=self.out, **kw)
+            self.out = ops.forward_backward(self.lat, self.theta, arc_scores=self.arc_scores, want_alpha_beta=False,
+                                            want_posterior=False, out=self.out, **kw)
         else:
-            return ops.backward(self.lat, self.theta, want_logbeta=False)
+            return ops.backward(self.lat, self.theta, arc_scores=self.arc_scores, want_logbeta=False)
         return self.out
 
     def reduce_loss(self, r):
@@ -400,6 +401,7 @@ def main():
     ap.add_argument("--torch-sum", action="store_true", help="reduce the loss with torch.sum instead of the kernel's fused total")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
+    ap.add_argument("--arc-scores", action="store_true", help="tuning: caller-supplied per-arc scores (the autograd path) in every mode")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU, no kernel, no number: ranks rendezvous over gloo, pack a few lattices, all-reduce a "
                          "scalar and rank 0 prints a line with value null (tests of the launcher on a CPU box)")
@@ -451,7 +453,8 @@ def main():
     alg_bytes = lat.algorithmic_bytes("forward_backward")
 
     fused = args.mode != "bwd" and not args.torch_sum and not args.graph  # a captured launch has one fixed slot
-    st = Stepper(lat, theta, dev, world, mode=args.mode, fused=fused)
+    asc = torch.randn(lat.total_arcs, device=dev) * 0.1 if args.arc_scores else None
+    st = Stepper(lat, theta, dev, world, mode=args.mode, fused=fused, arc_scores=asc)
 
     # --graph: a step is launched by replaying a HIP graph of the forward-backward kernel (the
     # engine allocates nothing, so one warm-up call makes it capturable); the reduction of the loss
@@ -481,7 +484,7 @@ def main():
 
     # the other per-GPU batch size of the BASELINE configs, every rank, same protocol, fewer steps
     aux = {}
-    default_shape = args.lattices_per_gpu == 0 and args.mode == "fb" and args.width == 16 and not args.graph
+    default_shape = args.lattices_per_gpu == 0 and args.mode == "fb" and args.width == 16 and not args.graph and not args.arc_scores
     if default_shape and not args.no_aux:
         B2 = 1024 if B == 256 else 256
         key = {256: "per_gpu_256", 1024: "per_gpu_1024"}

@@ -204,12 +204,9 @@ typedef struct nfst_scores {
   const float *theta;
   int64_t theta_stride;
   const float *arc_scores;
-  float *slot_ws;          /* workspace of fwd_slots + bwd_slots floats, required by nfst_backward and
-                              nfst_forward_backward when the batch is weighted or arc_scores is given: the launch
-                              first writes the per-arc extras in tile-slot order into it, so that the sweeps
-                              stream them like the arc records instead of gathering them arc by arc */
-  int64_t slot_ws_ready;   /* non-zero: slot_ws already holds the extras of exactly this batch and arc_scores
-                              (e.g. a weighted batch without arc_scores launched before): skip refilling it */
+  float *reserved_ws;      /* unused since ABI 5 (was a workspace for slot-ordered extras: the sweeps now gather
+                              per-arc extras inside the kernel, on otherwise idle waves); pass NULL */
+  int64_t reserved_flag;   /* unused, pass 0 */
 } nfst_scores;
 
 /*

@@ -47,8 +47,8 @@ class Batch(C.Structure):
 
 
 class Scores(C.Structure):
-    _fields_ = [("theta", C.c_void_p), ("theta_stride", C.c_int64), ("arc_scores", C.c_void_p), ("slot_ws", C.c_void_p),
-                ("slot_ws_ready", C.c_int64)]
+    _fields_ = [("theta", C.c_void_p), ("theta_stride", C.c_int64), ("arc_scores", C.c_void_p), ("reserved_ws", C.c_void_p),
+                ("reserved_flag", C.c_int64)]
 
 
 class StepExtras(C.Structure):

@@ -151,12 +151,7 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   const LdsPlan plan(lat->max_rows, lat->vocab);
   RingCfg cfg;
   if (!ring_config(plan, false, extra, lat->n_lattices <= cu_count(), &cfg)) return NFST_ERR_LIMIT;
-  if (extra) {  // slot-ordered extras of the backward program
-    if (!scores->slot_ws) return NFST_ERR_ARG;
-    if (lat->bwd_slots > 0 && !scores->slot_ws_ready)
-      hipLaunchKernelGGL(k_slot_extras, dim3((unsigned)((lat->bwd_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *lat,
-                         *scores, (int64_t)lat->fwd_slots, (int64_t)(lat->fwd_slots + lat->bwd_slots));
-  }
+  if (extra && ((uintptr_t)lat->bwd_perm & 15)) return NFST_ERR_ARG;  // the extras waves read the slot -> arc map 16 bytes at a time
   const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.bwd_bytes(R, RS, extra);
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
@@ -166,8 +161,9 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
                        (hipStream_t)stream, *lat, *scores, R, RS, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
   // 512 threads: loader + decoder + sweep (deep); 256 threads: self-loading decoder + sweep
-  if (!cfg.self) { if (extra) NFST_LAUNCH_BWD(512, true) else NFST_LAUNCH_BWD(512, false) }
-  else { if (extra) NFST_LAUNCH_BWD(256, true) else NFST_LAUNCH_BWD(256, false) }
+  const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
+  if (!cfg.self) { if (both) NFST_LAUNCH_BWD(512, 2) else if (extra) NFST_LAUNCH_BWD(512, 1) else NFST_LAUNCH_BWD(512, 0) }
+  else { if (both) NFST_LAUNCH_BWD(256, 2) else if (extra) NFST_LAUNCH_BWD(256, 1) else NFST_LAUNCH_BWD(256, 0) }
 #undef NFST_LAUNCH_BWD
   return hip_status(hipGetLastError());
 }
@@ -182,6 +178,7 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (logz_total && (total_slot < 0 || total_slot > 2)) return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
+  const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
   const int cus = cu_count();
   RingCfg cfg;
@@ -193,13 +190,8 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
                      !(no_fused && no_fused[0] == '1');
   if (fused) cfg = {0, 0, lat->n_lattices > cus};
   else if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
-  if (extra) {  // slot-ordered extras of both programs
-    if (!scores->slot_ws) return NFST_ERR_ARG;
-    const int64_t n = lat->fwd_slots + lat->bwd_slots;
-    if (n > 0 && !scores->slot_ws_ready)
-      hipLaunchKernelGGL(k_slot_extras, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *lat, *scores,
-                         (int64_t)0, n);
-  }
+  if (extra && (((uintptr_t)lat->fwd_perm | (uintptr_t)lat->bwd_perm | (uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 15))
+    return NFST_ERR_ARG;  // (maps and extras are read 16 bytes at a time)
   const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
@@ -212,8 +204,8 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   }
 #define NFST_LAUNCH_FUSED(NT)                                                                            \
   {                                                                                                     \
-    if ((rc = set_lds(k_forward_backward<NT, false, true>, lds))) return rc;                            \
-    hipLaunchKernelGGL((k_forward_backward<NT, false, true>), dim3(lat->n_lattices), dim3(NT), (size_t)lds, \
+    if ((rc = set_lds(k_forward_backward<NT, 0, true>, lds))) return rc;                                \
+    hipLaunchKernelGGL((k_forward_backward<NT, 0, true>), dim3(lat->n_lattices), dim3(NT), (size_t)lds,     \
                        (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, logz_total,    \
                        (int)total_slot, posterior, grad_theta, (float2 *)beta_me);                      \
   }
@@ -225,9 +217,11 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     // fused sweep's 32 AGPRs, and it then spills into AGPRs -- into the ones the sweep stages tiles in)
     if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FUSED(512)
     else NFST_LAUNCH_FUSED(256)
-  } else if (!cfg.self) { if (extra) NFST_LAUNCH_FB(1024, true) else NFST_LAUNCH_FB(1024, false) }
-  else if (lat->n_lattices <= 2 * cus) { if (extra) NFST_LAUNCH_FB(512, true) else NFST_LAUNCH_FB(512, false) }
-  else { if (extra) NFST_LAUNCH_FB(256, true) else NFST_LAUNCH_FB(256, false) }
+  } else if (!cfg.self) { if (both) NFST_LAUNCH_FB(1024, 2) else if (extra) NFST_LAUNCH_FB(1024, 1) else NFST_LAUNCH_FB(1024, 0) }
+  else if (both) NFST_LAUNCH_FB(512, 2)  // (the weight waves are waves 4 .. 7)
+  else if (extra) NFST_LAUNCH_FB(512, 1)
+  else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512, 0)
+  else NFST_LAUNCH_FB(256, 0)
 #undef NFST_LAUNCH_FB
 #undef NFST_LAUNCH_FUSED
   return hip_status(hipGetLastError());

@@ -34,6 +34,27 @@ __device__ __forceinline__ ME exp_split(float x) {
   return r;
 }
 
+// the same numbers without a branch (the range test is a select): for code that keeps loads in flight
+__device__ __forceinline__ ME exp_split_nb(float x) {
+  const bool live = x > -9.0e7f;
+  const float xc = fminf(live ? x : 0.0f, 9.0e7f);
+  const float kf = rintf(xc * 1.44269504088896341f);
+  float t = fmaf(-kf, 0.693145751953125f, xc);
+  t = fmaf(-kf, 1.42860682030941723e-6f, t);
+  float p = 1.0f / 5040.0f;
+  p = fmaf(p, t, 1.0f / 720.0f);
+  p = fmaf(p, t, 1.0f / 120.0f);
+  p = fmaf(p, t, 1.0f / 24.0f);
+  p = fmaf(p, t, 1.0f / 6.0f);
+  p = fmaf(p, t, 0.5f);
+  p = fmaf(p, t, 1.0f);
+  p = fmaf(p, t, 1.0f);
+  ME r;
+  r.m = live ? p : 0.0f;
+  r.e = live ? (int)kf : kEZero;
+  return r;
+}
+
 // normalise a sum to mantissa in [0.5, 1).  A zero sum keeps mantissa 0 (frexp(0) = 0,
 // exponent 0): its exponent stays near kEZero, which never wins a max against a real
 // term, so no select is needed.

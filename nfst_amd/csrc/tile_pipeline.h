@@ -38,7 +38,6 @@
 // sweep: deep when a workgroup has a CU's LDS to itself, shallow when two share it
 constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = kDmaAheadShared + 1;
 constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
-constexpr int kRawWordsX = kRawWords + 64 * 4;  // + the slots' canonical arc ids (kernels with per-arc extras)
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
 // program format code (meta word, bits 0..7): 1, 2, 4 = slots per lane with 32-bit records and a
 // separate control block; 8 = the compact tile: four slots per lane, 16 bytes per lane = control
@@ -405,34 +404,28 @@ __device__ __forceinline__ void vm_wait() {  // at most N vector-memory operatio
 }
 
 // LDS-DMA instructions per tile
-template <int F, bool EXTRA>
+template <int F>
 struct DmaOps {
-  static constexpr int value = F == 8 ? (EXTRA ? 2 : 1) : (F == 2 ? 3 : 2) + (EXTRA ? (F == 2 ? 2 : 1) : 0);
+  static constexpr int value = F == 8 ? 1 : (F == 2 ? 3 : 2);
 };
 
-// raw staging slot: [64 control words][64 U records]([64 U slot-ordered extra log weights]); compact
-// tiles: [64 x (control word, 3 record words)]([256 extras]).  `perm` is that slot-ordered stream.
-template <int F, bool EXTRA>
-__device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *perm, int tile, uint32_t slot_addr, int lane) {
+// raw staging slot: [64 control words][64 U records]; compact tiles: [64 x (control word, 3 record words)]
+template <int F>
+__device__ __forceinline__ void tile_issue(const uint32_t *g, int tile, uint32_t slot_addr, int lane) {
   constexpr int U = fmt_u(F);
   const uint32_t *src = g + (size_t)tile * fmt_words(F);
-  const int32_t *q = perm + (size_t)tile * (64 * U);
   if (F == 8) {
     lds_dma16(src + lane * 4, slot_addr);
-    if (EXTRA) lds_dma16(q + lane * 4, slot_addr + 1024);
     return;
   }
   lds_dma4(src + lane, slot_addr);
   if (U == 4) {
     lds_dma16(src + 64 + lane * 4, slot_addr + 256);
-    if (EXTRA) lds_dma16(q + lane * 4, slot_addr + 256 + 1024);
   } else if (U == 2) {
     lds_dma4(src + 64 + lane, slot_addr + 256);
     lds_dma4(src + 128 + lane, slot_addr + 512);
-    if (EXTRA) { lds_dma4(q + lane, slot_addr + 768); lds_dma4(q + 64 + lane, slot_addr + 1024); }
   } else {
     lds_dma4(src + 64 + lane, slot_addr + 256);
-    if (EXTRA) lds_dma4(q + lane, slot_addr + 512);
   }
 }
 
@@ -441,17 +434,15 @@ __device__ __forceinline__ void tile_issue(const uint32_t *g, const int32_t *per
 // staging ring; the decoder's `land` (tiles decoded) tells which staging slots are free.
 // part 1 (kernel entry, before anything else): the first ring-full needs no hand-shake,
 // so it is in flight while the workgroup initialises
-template <bool EXTRA>
-__device__ __forceinline__ void loader_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
-                                             int RS, int lane) {
-  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+__device__ __forceinline__ void loader_start(int U, const uint32_t *g, int n_tiles, uint32_t *raw, int RS, int lane) {
+  constexpr uint32_t RB = kRawWords * 4;
   const uint32_t raw_base = lds_addr(raw);
   const int n = min(n_tiles, RS);
   for (int d = 0; d < n; ++d) {
-    if (U == 8) tile_issue<8, EXTRA>(g, perm, d, raw_base + d * RB, lane);
-    else if (U == 4) tile_issue<4, EXTRA>(g, perm, d, raw_base + d * RB, lane);
-    else if (U == 2) tile_issue<2, EXTRA>(g, perm, d, raw_base + d * RB, lane);
-    else tile_issue<1, EXTRA>(g, perm, d, raw_base + d * RB, lane);
+    if (U == 8) tile_issue<8>(g, d, raw_base + d * RB, lane);
+    else if (U == 4) tile_issue<4>(g, d, raw_base + d * RB, lane);
+    else if (U == 2) tile_issue<2>(g, d, raw_base + d * RB, lane);
+    else tile_issue<1>(g, d, raw_base + d * RB, lane);
   }
 }
 
@@ -470,12 +461,12 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 // whole program issued) it publishes the oldest unpublished tile with the exact count.
 // `land` is the decoder's progress: when it publishes tile t the raw words of tiles 0 .. t+1
 // are in its registers, so the staging slot of tile i is certainly free once land >= i + 1.
-template <int F, bool EXTRA, int AHEAD>
-__device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int RS,
+template <int F, int AHEAD>
+__device__ __forceinline__ void tile_loader(const uint32_t *g, int n_tiles, uint32_t *raw, int RS,
                                             const int *land, int *rland, int lane) {
-  constexpr int OPS = DmaOps<F, EXTRA>::value;
+  constexpr int OPS = DmaOps<F>::value;
   static_assert(OPS * AHEAD <= 63, "vmcnt is 6 bits");
-  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  constexpr uint32_t RB = kRawWords * 4;
   const uint32_t raw_base = lds_addr(raw), raw_end = raw_base + RS * RB;
   int issued = min(n_tiles, RS);  // loader_start issued these
   uint32_t rb = raw_base;         // slot of tile `issued` (the ring has wrapped once)
@@ -498,7 +489,7 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
       }
       continue;
     }
-    tile_issue<F, EXTRA>(g, perm, issued, rb, lane);
+    tile_issue<F>(g, issued, rb, lane);
     ++issued;
     rb = (rb + RB == raw_end) ? raw_base : rb + RB;
     if (issued - pub > AHEAD) {
@@ -517,14 +508,13 @@ __device__ __forceinline__ void tile_loader(const uint32_t *g, const int32_t *pe
 // "write slot -> store land" / "load land -> read slot" need no barrier.
 // one tile in the decoder's registers: control word, byte offset of every operand's value,
 // 8 x label of every record, canonical arcs (only with per-arc extras)
-template <int U, bool EXTRA>
+template <int U, int EXTRA>
 struct RawRegs {
   uint32_t ctl;
   uint32_t opoff[U];
   uint32_t lab8[U];
-  int32_t pm[EXTRA ? U : 1];  // bits of the slots' extra log weights (kernels with per-arc extras)
 };
-template <int F, bool EXTRA>
+template <int F, int EXTRA>
 __device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<fmt_u(F), EXTRA> &w) {
   constexpr int U = fmt_u(F);
   uint32_t rc[U];
@@ -539,30 +529,17 @@ __device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<fmt_u(F
       w.opoff[j] = (r[j % 4] << 3) & 0xfff8u;   // state (13 bits) x 8
       w.lab8[j] = (r[j % 4] >> 10) & 0x3ff8u;   // label (11 bits) x 8
     }
-    if (EXTRA) {
-      const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 1024 + lane * 16);
-      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
-    }
     return;
   }
   w.ctl = *(const lds_u32 *)(uintptr_t)(rb + lane * 4);
   if (U == 4) {
     const v4u v = *(const lds_v4u *)(uintptr_t)(rb + 256 + lane * 16);
     rc[0] = v.x; rc[1 % U] = v.y; rc[2 % U] = v.z; rc[3 % U] = v.w;
-    if (EXTRA) {
-      const v4u a = *(const lds_v4u *)(uintptr_t)(rb + 256 + 1024 + lane * 16);
-      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y; w.pm[EXTRA ? 2 % U : 0] = (int)a.z; w.pm[EXTRA ? 3 % U : 0] = (int)a.w;
-    }
   } else if (U == 2) {
     const v2u v = *(const lds_v2u *)(uintptr_t)(rb + 256 + lane * 8);
     rc[0] = v.x; rc[1 % U] = v.y;
-    if (EXTRA) {
-      const v2u a = *(const lds_v2u *)(uintptr_t)(rb + 768 + lane * 8);
-      w.pm[0] = (int)a.x; w.pm[EXTRA ? 1 % U : 0] = (int)a.y;
-    }
   } else {
     rc[0] = *(const lds_u32 *)(uintptr_t)(rb + 256 + lane * 4);
-    if (EXTRA) w.pm[0] = (int)*(const lds_u32 *)(uintptr_t)(rb + 512 + lane * 4);
   }
 #pragma unroll
   for (int j = 0; j < U; ++j) {
@@ -575,36 +552,35 @@ __device__ __forceinline__ void raw_fetch(uint32_t rb, int lane, RawRegs<fmt_u(F
 // fewer, busier waves): it keeps AHEAD tiles in flight itself -- self_start() at kernel
 // entry, one issue per iteration -- and a counted wait replaces the rland flag.  The
 // staging ring then has AHEAD + 1 slots.
-template <int F, bool EXTRA, int AHEAD>
-__device__ __forceinline__ void self_start_u(const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw, int lane) {
-  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+template <int F, int AHEAD>
+__device__ __forceinline__ void self_start_u(const uint32_t *g, int n_tiles, uint32_t *raw, int lane) {
+  constexpr uint32_t RB = kRawWords * 4;
   const uint32_t raw_base = lds_addr(raw);
   const int last = max(n_tiles - 1, 0);
 #pragma unroll
   for (int d = 0; d < AHEAD; ++d)  // short programs copy their last tile again: the count stays constant
-    tile_issue<F, EXTRA>(g, perm, min(d, last), raw_base + d * RB, lane);
+    tile_issue<F>(g, min(d, last), raw_base + d * RB, lane);
 }
-template <bool EXTRA, int AHEAD>
-__device__ __forceinline__ void self_start(int U, const uint32_t *g, const int32_t *perm, int n_tiles, uint32_t *raw,
-                                           int lane) {
-  if (U == 8) self_start_u<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
-  else if (U == 4) self_start_u<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
-  else if (U == 2) self_start_u<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
-  else self_start_u<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, lane);
+template <int AHEAD>
+__device__ __forceinline__ void self_start(int U, const uint32_t *g, int n_tiles, uint32_t *raw, int lane) {
+  if (U == 8) self_start_u<8, AHEAD>(g, n_tiles, raw, lane);
+  else if (U == 4) self_start_u<4, AHEAD>(g, n_tiles, raw, lane);
+  else if (U == 2) self_start_u<2, AHEAD>(g, n_tiles, raw, lane);
+  else self_start_u<1, AHEAD>(g, n_tiles, raw, lane);
 }
 
-template <int F, bool EXTRA, bool SELF, int AHEAD>
+template <int F, int EXTRA, bool SELF, int AHEAD>
 __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, int RS, const int *rland,
-                                             const uint32_t *g, const int32_t *perm,
+                                             const uint32_t *g, const int *xland, int NE,
                                              uint32_t *ring, int R, const int *prog, int *land, const float2 *val,
-                                             const float2 *th_, const Extra /*ex: extras arrive with the tiles*/, int lane) {
+                                             const float2 *th_, int lane) {
   if (n_tiles <= 0) {
     if (SELF) vm_wait<0>();
     return;
   }
   constexpr int U = fmt_u(F);
-  constexpr int OPS = DmaOps<F, EXTRA>::value;
-  constexpr uint32_t RB = (EXTRA ? kRawWordsX : kRawWords) * 4;
+  constexpr int OPS = DmaOps<F>::value;
+  constexpr uint32_t RB = kRawWords * 4;
   constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
   const uint32_t th_base = lds_addr(th_);
   const uint32_t val_base = lds_addr(val);
@@ -622,7 +598,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     if (SELF) {
       // one more tile goes in flight (past the end the last tile is copied again into a slot
       // nobody reads, so that the count stays exact); then at most AHEAD are
-      tile_issue<F, EXTRA>(g, perm, min(issue_next, last), rb_issue, lane);
+      tile_issue<F>(g, min(issue_next, last), rb_issue, lane);
       ++issue_next;
       rb_issue = (rb_issue + RB == raw_end) ? raw_base : rb_issue + RB;
       vm_wait<OPS * AHEAD>();
@@ -638,6 +614,10 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 #pragma unroll
     for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + w.lab8[j]);
   };
+  // per-arc extras: the weight wave (t mod NE; NE is a power of two) writes the weights of tile t into the
+  // ring slot and then publishes t + 1 in its flag; the flag is read at the start of the iteration
+  const uint32_t xl_base = lds_addr(xland);
+  int x_peek = 0;
   // iteration t: `cur` = raw words of tile t, `tw` = its label weights (LDS gathers issued
   // one iteration earlier); fetches the raw words of tile t+1 into `nxt` and, at the end,
   // issues the gathers of its label weights into `twn`
@@ -650,6 +630,7 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     if (SELF) freed = max(freed, __builtin_amdgcn_readfirstlane(prog_peek));
     wait_raw(min(t + 2, n_tiles));
     raw_fetch<F, EXTRA>(rb, lane, nxt);
+    if (EXTRA) x_peek = (int)*(const volatile lds_u32 *)(uintptr_t)(xl_base + (uint32_t)(t & (NE - 1)) * 4);
     if (SELF) prog_peek = lds_flag_load(prog);
     asm volatile("" ::: "memory");
     // --- control word and operand addresses: the packer's byte offsets + the array's base
@@ -668,16 +649,13 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     else if (U == 2) *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
     else *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
     if (EXTRA) {
-      // per-arc extras (table weights + caller scores) arrive in slot order with the tile
-      // (k_slot_extras wrote them before the sweeps): no gather here
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const ME x = exp_split(__int_as_float(cur.pm[j]));
-        tw[j].x *= x.m;
-        tw[j].y = __int_as_float(__float_as_int(tw[j].y) + x.e);
+      // the arc weights of this tile (label weight x per-arc extras) come from the weight waves: wait for them
+      int seen = __builtin_amdgcn_readfirstlane(x_peek);
+      while (__builtin_expect(seen < t + 1, 0)) {
+        seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)(xl_base + (uint32_t)(t & (NE - 1)) * 4));
+        if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
       }
-    }
-    if (U == 4) {
+    } else if (U == 4) {
       *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{tw[0].x, tw[0].y, tw[1 % U].x, tw[1 % U].y};
       *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{tw[2 % U].x, tw[2 % U].y, tw[3 % U].x, tw[3 % U].y};
     } else if (U == 2) {
@@ -690,13 +668,13 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
     // are in registers
     lds_flag_store(land, t + 1);
     sb = (sb + SB == ring_end) ? ring_base : sb + SB;
-    gather_weights(nxt, twn);
+    if (!EXTRA) gather_weights(nxt, twn);
   };
   RawRegs<U, EXTRA> ra, rbb;
   v2f ta[U], tb[U];
   wait_raw(1);
   raw_fetch<F, EXTRA>(rb, lane, ra);
-  gather_weights(ra, ta);
+  if (!EXTRA) gather_weights(ra, ta);
   // two iterations per trip so that the register roles alternate without copies
   for (int t = 0; t < n_tiles; t += 2) {
     step(t, ra, ta, rbb, tb);
@@ -705,6 +683,143 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
   }
   if (SELF) vm_wait<0>();  // nothing of the staging ring stays in flight
 }
+
+// ---- weight waves (kernels with per-arc extras) -----------------------------------
+// Per-arc extras (table weights, caller scores; canonical arc order in HBM) reach the sweeps without a
+// pre-pass: NE otherwise idle waves per sweep compute the arc weights of the decoded tiles -- label
+// weight x exp(extras) as (mantissa, exponent) pairs -- and write them straight into the decoded ring;
+// the decoder then only writes control words and operand addresses (it is lighter than without extras)
+// and publishes a tile when the weight wave's flag says its weights are there.  Wave ei takes tiles ei,
+// ei + NE, ...: the tile's records and slot -> arc map of tile i+4 (its own numbering: two coalesced
+// loads), the gathers of tile i+2 (after the first touch a lattice's 80 KB of scores are L2 hits) and the
+// arithmetic of tile i are in flight together.  A ring slot is free when the sweep has consumed the
+// tile R earlier (`prog`).  Empty slots and carry records (arc -1) load arc 0 and ignore it.
+// Straight-line code (the range test of exp_split is a select; EXTRA = 1: one array, 2: table weights
+// and caller scores): hipcc keeps counted s_waitcnt only where no branch lies between a load and its use.
+// Measured at 256 lattices: gathering both arrays when only one exists doubled the vector-L1 lookups
+// (64 per gather instruction) and slowed the tile stream of the loaders by a third.
+template <int F, int NE, bool BOTH>
+struct WeightWave {
+  static constexpr int U = fmt_u(F);
+  struct P { int a[U]; uint32_t lab8[U]; };
+  struct G { float w[U], s[BOTH ? U : 1]; uint32_t valid; uint32_t lab8[U]; };
+  P p0, p1, p2;
+  G g0, g1, g2;
+  const float *bw, *bs;
+  const int32_t *perm;
+  const uint32_t *prog_words;
+  int n_mine, last, ei;
+
+  __device__ __forceinline__ P ld_tile(int i, int lane) const {
+    P p;
+    const int t = min(ei + i * NE, last);
+    const int32_t *q = perm + (size_t)t * (64 * U) + lane * U;
+    const uint32_t *g = prog_words + (size_t)t * fmt_words(F);
+    if (U == 4) {
+      const int4 v = *reinterpret_cast<const int4 *>(q);
+      p.a[0] = v.x; p.a[1 % U] = v.y; p.a[2 % U] = v.z; p.a[3 % U] = v.w;
+      const uint4 x = *reinterpret_cast<const uint4 *>(g + (F == 8 ? 0 : 64) + lane * 4);
+      if (F == 8) {
+        const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
+#pragma unroll
+        for (int j = 0; j < U; ++j) p.lab8[j] = (r[j % 4] >> 10) & 0x3ff8u;
+      } else {
+        const uint32_t r[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < U; ++j) p.lab8[j] = (r[j % 4] >> 16) << 3;
+      }
+    } else if (U == 2) {
+      const int2 v = *reinterpret_cast<const int2 *>(q);
+      p.a[0] = v.x; p.a[1 % U] = v.y;
+      const uint2 x = *reinterpret_cast<const uint2 *>(g + 64 + lane * 2);
+      p.lab8[0] = (x.x >> 16) << 3; p.lab8[1 % U] = (x.y >> 16) << 3;
+    } else {
+      p.a[0] = q[0];
+      p.lab8[0] = (g[64 + lane] >> 16) << 3;
+    }
+    return p;
+  }
+  __device__ __forceinline__ G issue(const P &p) const {
+    G g;
+    g.valid = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int a = max(p.a[j], 0);
+      g.w[j] = bw[a];
+      if (BOTH) g.s[j] = bs[a];
+      g.valid |= (p.a[j] >= 0 ? 1u : 0u) << j;
+      g.lab8[j] = p.lab8[j];
+    }
+    return g;
+  }
+  // kernel entry (right behind the meta record): the records and maps of this wave's first tiles are in
+  // flight while the workgroup initialises; the gathers of its first two tiles follow before the barrier
+  __device__ __forceinline__ void start_maps(const uint32_t *prog_, const int32_t *perm_, int n_tiles, const Extra ex, int ei_, int lane) {
+    perm = perm_; prog_words = prog_; ei = ei_;
+    n_mine = n_tiles > ei ? (n_tiles - ei + NE - 1) / NE : 0;
+    last = max(n_tiles - 1, 0);
+    bw = ex.arc_w ? ex.arc_w : ex.arc_scores;
+    bs = ex.arc_scores;
+    if (n_tiles <= 0) { n_mine = 0; return; }
+    p0 = ld_tile(0, lane); p1 = ld_tile(1, lane); p2 = ld_tile(2, lane);
+  }
+  __device__ __forceinline__ void start_gathers(int lane) {
+    if (n_mine <= 0) return;
+    g0 = issue(p0);
+    p0 = ld_tile(3, lane);
+    g1 = issue(p1);
+  }
+  __device__ __forceinline__ void run(uint32_t *ring, int R, const int *prog, int *xland, const float2 *th_, int lane) {
+    if (n_mine <= 0) return;
+    constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
+    const uint32_t ring_base = lds_addr(ring), prog_a = lds_addr(prog), xl_a = lds_addr(xland) + (uint32_t)ei * 4;
+    const uint32_t th_base = lds_addr(th_);
+    int prog_seen = 0;
+    auto process = [&](int i, const G &g) {
+      const int t = ei + i * NE;
+      v2f tw[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + g.lab8[j]);
+      v2f o[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const float xs = BOTH ? g.w[j] + g.s[BOTH ? j : 0] : g.w[j];
+        const ME x = exp_split_nb(((g.valid >> j) & 1u) ? xs : 0.0f);
+        o[j] = v2f{tw[j].x * x.m, __int_as_float(__float_as_int(tw[j].y) + x.e)};
+      }
+      while (__builtin_expect(prog_seen < t - R + 1, 0)) {  // the slot's previous tile is consumed
+        prog_seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)prog_a);
+        if (prog_seen < t - R + 1) __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+      const uint32_t sb = ring_base + (uint32_t)(t % R) * SB;
+      if (U == 4) {
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{o[0].x, o[0].y, o[1 % U].x, o[1 % U].y};
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{o[2 % U].x, o[2 % U].y, o[3 % U].x, o[3 % U].y};
+      } else if (U == 2) {
+        *(lds_v4f *)(uintptr_t)(sb + 256 + 512 + lane * 16) = v4f{o[0].x, o[0].y, o[1 % U].x, o[1 % U].y};
+      } else {
+        *(lds_v2f *)(uintptr_t)(sb + 256 + 256 + lane * 8) = o[0];
+      }
+      asm volatile("" ::: "memory");
+      *(volatile lds_u32 *)(uintptr_t)xl_a = (uint32_t)(t + 1);
+    };
+    // iteration i: the gathers of tile i+2 (its records and map were loaded two iterations ago), the
+    // records and map of tile i+4, then tile i itself; register roles are compile-time: three
+    // iterations per trip
+#define NFST_X_STEP(PU, GN, PL, GC)  \
+    GN = issue(PU);                  \
+    PL = ld_tile(i + 4, lane);       \
+    process(i, GC);
+    for (int i0 = 0; i0 < n_mine; i0 += 3) {
+      int i = i0;
+      NFST_X_STEP(p2, g2, p1, g0) if (++i >= n_mine) break;
+      NFST_X_STEP(p0, g0, p2, g1) if (++i >= n_mine) break;
+      NFST_X_STEP(p1, g1, p0, g2)
+    }
+#undef NFST_X_STEP
+  }
+};
 
 // decoded tile in the sweep wave's registers
 template <int U>
@@ -836,13 +951,15 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
   }
 }
 
-// role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder.
-// flags: [0] prog [1] land [2] rland
-template <bool EXTRA, bool SELF, int AHEAD>
+// role dispatch: role 0 sweeps, role 1 decodes for it, role 2 loads for the decoder (the extras waves
+// of kernels with per-arc extras are driven by the kernels: their loads start at kernel entry).
+// flags: [0] prog [1] land [2] rland [4 .. 4 + NE) the extras waves' progress
+constexpr int kSweepFlags = 8;
+template <int EXTRA, bool SELF, int AHEAD, int NE>
 __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *raw, int RS, const uint32_t *g,
-                                          const int32_t *perm, int n_tiles, uint32_t *ring, int R, int *flags,
-                                          float2 *val, const float2 *th, const Extra ex, int lane) {
-  int *prog = flags, *land = flags + 1, *rland = flags + 2;
+                                          int n_tiles, uint32_t *ring, int R, int *flags,
+                                          float2 *val, const float2 *th, int lane) {
+  int *prog = flags, *land = flags + 1, *rland = flags + 2, *xland = flags + 4;
   if (role == 0) {
     if (U == 8) U = 4;  // the sweep only sees decoded tiles
     if (wide) {
@@ -855,15 +972,45 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
       else tile_sweep<1, false>(n_tiles, ring, R, prog, land, lane);
     }
   } else if (role == 1) {
-    if (U == 8) tile_decoder<8, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
-    else if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
-    else if (U == 2) tile_decoder<2, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
-    else tile_decoder<1, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, perm, ring, R, prog, land, val, th, ex, lane);
-  } else if (!SELF) {
-    if (U == 8) tile_loader<8, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
-    else if (U == 4) tile_loader<4, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
-    else if (U == 2) tile_loader<2, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
-    else tile_loader<1, EXTRA, AHEAD>(g, perm, n_tiles, raw, RS, land, rland, lane);
+    if (U == 8) tile_decoder<8, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, xland, NE, ring, R, prog, land, val, th, lane);
+    else if (U == 4) tile_decoder<4, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, xland, NE, ring, R, prog, land, val, th, lane);
+    else if (U == 2) tile_decoder<2, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, xland, NE, ring, R, prog, land, val, th, lane);
+    else tile_decoder<1, EXTRA, SELF, AHEAD>(n_tiles, raw, RS, rland, g, xland, NE, ring, R, prog, land, val, th, lane);
+  } else if (role == 2) {
+    if (!SELF) {
+      if (U == 8) tile_loader<8, AHEAD>(g, n_tiles, raw, RS, land, rland, lane);
+      else if (U == 4) tile_loader<4, AHEAD>(g, n_tiles, raw, RS, land, rland, lane);
+      else if (U == 2) tile_loader<2, AHEAD>(g, n_tiles, raw, RS, land, rland, lane);
+      else tile_loader<1, AHEAD>(g, n_tiles, raw, RS, land, rland, lane);
+    }
+  }
+}
+
+// a weight wave's part of a sweep: compact programs were started at kernel entry (x8), the rarer
+// formats start here
+template <int NE, bool BOTH>
+__device__ __forceinline__ void run_weights(WeightWave<8, NE, BOTH> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
+                                            int n_tiles, const Extra ex, int ei, uint32_t *ring, int R, int *flags,
+                                            const float2 *th, int lane) {
+  const int *prog = flags;
+  int *xland = flags + 4;
+  if (F == 8) {
+    x8.run(ring, R, prog, xland, th, lane);
+  } else if (F == 4) {
+    WeightWave<4, NE, BOTH> x;
+    x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
+    x.start_gathers(lane);
+    x.run(ring, R, prog, xland, th, lane);
+  } else if (F == 2) {
+    WeightWave<2, NE, BOTH> x;
+    x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
+    x.start_gathers(lane);
+    x.run(ring, R, prog, xland, th, lane);
+  } else {
+    WeightWave<1, NE, BOTH> x;
+    x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
+    x.start_gathers(lane);
+    x.run(ring, R, prog, xland, th, lane);
   }
 }
 

@@ -29,7 +29,7 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-def _scores(lat: LatticeBatch, theta: torch.Tensor, arc_scores: Optional[torch.Tensor], ws_need: Optional[str] = None):
+def _scores(lat: LatticeBatch, theta: torch.Tensor, arc_scores: Optional[torch.Tensor]):
     """nfst_scores + the tensors that must stay alive during the launch."""
     if theta.dtype != torch.float32 or theta.device != lat.device:
         theta = theta.to(device=lat.device, dtype=torch.float32)
@@ -46,23 +46,7 @@ def _scores(lat: LatticeBatch, theta: torch.Tensor, arc_scores: Optional[torch.T
         arc_scores = arc_scores.to(device=lat.device, dtype=torch.float32).contiguous()
         if arc_scores.shape != (lat.total_arcs,):
             raise ValueError(f"arc_scores must be [{lat.total_arcs}] in canonical arc order")
-    ws, ready = None, 0
-    if ws_need is not None and (arc_scores is not None or lat.weighted):
-        # per-batch workspace for the slot-ordered extras (fwd_slots + bwd_slots floats), allocated once.
-        # ws_need: "fb" (both programs) or "bwd".  The table weights of a weighted batch are static:
-        # without arc_scores the part an earlier launch filled stays valid.
-        ws = lat.__dict__.get("_slot_ws")
-        if ws is None or ws.device != lat.device:
-            ws = torch.empty(lat.fwd_slots + lat.bwd_slots, dtype=torch.float32, device=lat.device)
-            lat.__dict__["_slot_ws"] = ws
-            lat.__dict__["_slot_ws_static"] = ""
-        have = lat.__dict__.get("_slot_ws_static", "")
-        ready = int(arc_scores is None and (have == "fb" or have == ws_need))
-        if arc_scores is not None:
-            lat.__dict__["_slot_ws_static"] = ""
-        elif not ready:
-            lat.__dict__["_slot_ws_static"] = ws_need
-    return _lib.Scores(theta.data_ptr(), stride, _ptr(arc_scores), _ptr(ws), ready), (theta, arc_scores, ws)
+    return _lib.Scores(theta.data_ptr(), stride, _ptr(arc_scores), None, 0), (theta, arc_scores)
 
 
 class BackwardResult(NamedTuple):
@@ -76,7 +60,7 @@ def backward(lat: LatticeBatch, theta, arc_scores=None, want_logbeta=True, want_
     """beta sweep + log Z.  Replaces FSAGRUScorer.compute_beta
     (/root/reference/src/modules/scorers.py:858-875)."""
     _need_gpu(lat)
-    sc, keep = _scores(lat, theta, arc_scores, "bwd")
+    sc, keep = _scores(lat, theta, arc_scores)
     dev = lat.device
     logbeta = torch.empty(lat.total_rows, dtype=torch.float32, device=dev) if want_logbeta else None
     z64 = torch.empty(lat.n_lattices, dtype=torch.float64, device=dev)
@@ -107,7 +91,7 @@ def forward_backward(lat: LatticeBatch, theta, arc_scores=None, want_alpha_beta=
     of 3 zeros, owned by the caller) receives sum_b log Z[b] in ``total[total_slot]`` without a
     reduction kernel; pass ``total_slot = step % 3`` (the launch clears the next slot)."""
     _need_gpu(lat)
-    sc, keep = _scores(lat, theta, arc_scores, "fb")
+    sc, keep = _scores(lat, theta, arc_scores)
     dev = lat.device
     f32 = dict(dtype=torch.float32, device=dev)
     if out is not None:

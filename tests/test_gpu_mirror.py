@@ -149,10 +149,11 @@ def test_neural_beta_scorer_matches_reference(dev, golden_dir):
     tr = tr.copy(); tr[-1, PAD] = tr.shape[0] - 1
     sc.set_masks(emission=torch.from_numpy(em)[None], transition=torch.from_numpy(tr)[None])
     sc.set_k(3)
-    beta = sc.compute_beta().cpu().numpy()
+    beta = sc.compute_beta().detach().cpu().numpy()
     assert beta.shape == (3, tr.shape[0]) and np.array_equal(beta[0], beta[2])
     np.testing.assert_allclose(beta[0], c["beta_per_sample"], rtol=5e-5)
     _, bhat = sc.compute_beta_hat()
+    bhat = bhat.detach()
     assert bhat.shape == (3, tr.shape[0], H) and float(bhat.abs().max()) <= 1.0
     # trainable as in tune_proposal (lightning.py:339-406): the scorer's parameters get gradients through
     # compute_beta (they match float64 autograd over the restatement in test_gpu_parity.py)
