@@ -31,7 +31,7 @@ struct LdsPlan {
 // Wave 0 sweeps the by-source program from the sink, wave 1 decodes for it, wave 2 loads
 // for the decoder; with per-arc extras the last four (two) waves are the extras waves; every wave
 // helps with the initialisation and the outputs.
-template <int NT, int EXTRA>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both
+template <int NT, int EXTRA>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both, 3 none but weight waves
 __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, int RS, float *logbeta,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   }
   // extras waves: the slot -> arc maps of their first tiles go in flight now, the first gathers before the barrier
   const bool x_wave = EXTRA != 0 && wv >= kFirstX;
-  WeightWave<8, kNE, EXTRA == 2> xw8;
+  WeightWave<8, kNE, EXTRA % 3> xw8;
   if (x_wave && m.bwd_u == 8) xw8.start_maps(lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, lane);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   }
   __syncthreads();
   if (x_wave) {
-    run_weights<kNE, EXTRA == 2>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, ring, R, flags, th, lane);
+    run_weights<kNE, EXTRA % 3>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, ring, R, flags, th, lane);
   } else if (wv < (kSelf ? 2 : 3))
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off,
               m.bwd_tiles, ring, R, flags, beta, th, lane);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
   uint32_t *ring = (uint32_t *)(gth + plan.v4);
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  constexpr bool has_extra = EXTRA != 0;
+  constexpr bool has_extra = EXTRA == 1 || EXTRA == 2;  // (3: no extras, but the weight waves write the label weights)
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // even waves work for the beta sweep, odd waves for alpha: waves 0 / 1 sweep, 2 / 3 decode,
   // 6 / 7 load (waves i, i+4, ... share a SIMD: the busy-polling loaders sit with the decoders,
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     loader_start(my_u, my_prog, my_tiles, my_raw, RS, lane);
   }
   // extras waves: the slot -> arc maps of their first tiles go in flight now, the first gathers before the barrier
-  WeightWave<8, kNE, EXTRA == 2> xw8;
+  WeightWave<8, kNE, EXTRA % 3> xw8;
   if (x_wave && my_u == 8) xw8.start_maps(my_prog, my_perm, my_tiles, ex, x_index, lane);
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       else FusedSweep<false>::run(my_prog, my_tiles, bwd_side ? beta : alpha, th, trash, lane);
     }
   } else if (x_wave) {
-    run_weights<kNE, EXTRA == 2>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th, lane);
+    run_weights<kNE, EXTRA % 3>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th, lane);
     if (kPre > 0 && want_post) preload_arcs();
   } else if (wv < 4 || (!kSelf && (wv == 6 || wv == 7))) {
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog,

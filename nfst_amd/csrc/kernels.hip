@@ -217,7 +217,12 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     // fused sweep's 32 AGPRs, and it then spills into AGPRs -- into the ones the sweep stages tiles in)
     if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FUSED(512)
     else NFST_LAUNCH_FUSED(256)
-  } else if (!cfg.self) { if (both) NFST_LAUNCH_FB(1024, 2) else if (extra) NFST_LAUNCH_FB(1024, 1) else NFST_LAUNCH_FB(1024, 0) }
+  } else if (!cfg.self) {
+    // without extras the weight waves still write the label weights (the decoder is lighter: 46.6 -> 45.5 us at 256
+    // lattices, 130.6 -> 126.4 us at 551 levels; profiles/r02_ab_ww.txt); NFST_WW=0 keeps them in the decoder (A/B runs)
+    const char *ww = getenv("NFST_WW");
+    if (both) NFST_LAUNCH_FB(1024, 2) else if (extra) NFST_LAUNCH_FB(1024, 1) else if (!(ww && ww[0] == '0')) NFST_LAUNCH_FB(1024, 3) else NFST_LAUNCH_FB(1024, 0)
+  }
   else if (both) NFST_LAUNCH_FB(512, 2)  // (the weight waves are waves 4 .. 7)
   else if (extra) NFST_LAUNCH_FB(512, 1)
   else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512, 0)

@@ -698,8 +698,9 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 // and caller scores): hipcc keeps counted s_waitcnt only where no branch lies between a load and its use.
 // Measured at 256 lattices: gathering both arrays when only one exists doubled the vector-L1 lookups
 // (64 per gather instruction) and slowed the tile stream of the loaders by a third.
-template <int F, int NE, bool BOTH>
+template <int F, int NE, int XM>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2)
 struct WeightWave {
+  static constexpr bool BOTH = XM == 2;
   static constexpr int U = fmt_u(F);
   struct P { int a[U]; uint32_t lab8[U]; };
   struct G { float w[U], s[BOTH ? U : 1]; uint32_t valid; uint32_t lab8[U]; };
@@ -715,9 +716,15 @@ struct WeightWave {
     const int t = min(ei + i * NE, last);
     const int32_t *q = perm + (size_t)t * (64 * U) + lane * U;
     const uint32_t *g = prog_words + (size_t)t * fmt_words(F);
+    if (XM == 0) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) p.a[j] = -1;
+    }
     if (U == 4) {
-      const int4 v = *reinterpret_cast<const int4 *>(q);
-      p.a[0] = v.x; p.a[1 % U] = v.y; p.a[2 % U] = v.z; p.a[3 % U] = v.w;
+      if (XM != 0) {
+        const int4 v = *reinterpret_cast<const int4 *>(q);
+        p.a[0] = v.x; p.a[1 % U] = v.y; p.a[2 % U] = v.z; p.a[3 % U] = v.w;
+      }
       const uint4 x = *reinterpret_cast<const uint4 *>(g + (F == 8 ? 0 : 64) + lane * 4);
       if (F == 8) {
         const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
@@ -729,12 +736,14 @@ struct WeightWave {
         for (int j = 0; j < U; ++j) p.lab8[j] = (r[j % 4] >> 16) << 3;
       }
     } else if (U == 2) {
-      const int2 v = *reinterpret_cast<const int2 *>(q);
-      p.a[0] = v.x; p.a[1 % U] = v.y;
+      if (XM != 0) {
+        const int2 v = *reinterpret_cast<const int2 *>(q);
+        p.a[0] = v.x; p.a[1 % U] = v.y;
+      }
       const uint2 x = *reinterpret_cast<const uint2 *>(g + 64 + lane * 2);
       p.lab8[0] = (x.x >> 16) << 3; p.lab8[1 % U] = (x.y >> 16) << 3;
     } else {
-      p.a[0] = q[0];
+      if (XM != 0) p.a[0] = q[0];
       p.lab8[0] = (g[64 + lane] >> 16) << 3;
     }
     return p;
@@ -745,7 +754,7 @@ struct WeightWave {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const int a = max(p.a[j], 0);
-      g.w[j] = bw[a];
+      g.w[j] = XM != 0 ? bw[a] : 0.0f;
       if (BOTH) g.s[j] = bs[a];
       g.valid |= (p.a[j] >= 0 ? 1u : 0u) << j;
       g.lab8[j] = p.lab8[j];
@@ -783,6 +792,7 @@ struct WeightWave {
       v2f o[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
+        if (XM == 0) { o[j] = tw[j]; continue; }
         const float xs = BOTH ? g.w[j] + g.s[BOTH ? j : 0] : g.w[j];
         const ME x = exp_split_nb(((g.valid >> j) & 1u) ? xs : 0.0f);
         o[j] = v2f{tw[j].x * x.m, __int_as_float(__float_as_int(tw[j].y) + x.e)};
@@ -988,8 +998,8 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
 
 // a weight wave's part of a sweep: compact programs were started at kernel entry (x8), the rarer
 // formats start here
-template <int NE, bool BOTH>
-__device__ __forceinline__ void run_weights(WeightWave<8, NE, BOTH> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
+template <int NE, int XM>
+__device__ __forceinline__ void run_weights(WeightWave<8, NE, XM> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
                                             int n_tiles, const Extra ex, int ei, uint32_t *ring, int R, int *flags,
                                             const float2 *th, int lane) {
   const int *prog = flags;
@@ -997,17 +1007,17 @@ __device__ __forceinline__ void run_weights(WeightWave<8, NE, BOTH> &x8, int F, 
   if (F == 8) {
     x8.run(ring, R, prog, xland, th, lane);
   } else if (F == 4) {
-    WeightWave<4, NE, BOTH> x;
+    WeightWave<4, NE, XM> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
     x.run(ring, R, prog, xland, th, lane);
   } else if (F == 2) {
-    WeightWave<2, NE, BOTH> x;
+    WeightWave<2, NE, XM> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
     x.run(ring, R, prog, xland, th, lane);
   } else {
-    WeightWave<1, NE, BOTH> x;
+    WeightWave<1, NE, XM> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
     x.run(ring, R, prog, xland, th, lane);
