@@ -31,7 +31,7 @@ struct LdsPlan {
 // Wave 0 sweeps the by-source program from the sink, wave 1 decodes for it, wave 2 loads
 // for the decoder; with per-arc extras the last four (two) waves are the extras waves; every wave
 // helps with the initialisation and the outputs.
-template <int NT, int EXTRA>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both, 3 none but weight waves
+template <int NT, int EXTRA>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both
 __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, int RS, float *logbeta,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   }
   // extras waves: the slot -> arc maps of their first tiles go in flight now, the first gathers before the barrier
   const bool x_wave = EXTRA != 0 && wv >= kFirstX;
-  WeightWave<8, kNE, EXTRA % 3> xw8;
+  WeightWave<8, kNE, EXTRA, false> xw8;
   if (x_wave && m.bwd_u == 8) xw8.start_maps(lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, lane);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   }
   __syncthreads();
   if (x_wave) {
-    run_weights<kNE, EXTRA % 3>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, ring, R, flags, th, lane);
+    run_weights<kNE, EXTRA, false>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, ring, R, flags, th, beta,
+                                   false, 0u, lane);
   } else if (wv < (kSelf ? 2 : 3))
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off,
               m.bwd_tiles, ring, R, flags, beta, th, lane);
@@ -116,7 +117,10 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // beta, odd ones for alpha (tile_pipeline.h).
 // FUSED: waves 0 / 1 load, decode and sweep by themselves (FusedSweep, tile_pipeline.h): no loader,
 // no decoder, no rings; every program of the batch is compact and there are no per-arc extras.
-template <int NT, int EXTRA, bool FUSED = false>
+// TW (1024 threads): tile waves -- no loader, no staging ring, no decoder: the eight waves 2, 3, 6, 7, 10, 11, 14, 15
+// (the SIMDs the sweep waves are not on) decode every fourth tile of their sweep's program straight from
+// HBM into the decoded ring, label weights and per-arc extras included (WeightWave<.., FULL>).
+template <int NT, int EXTRA, bool FUSED = false, bool TW = false>
 __global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, int R, int RS, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, double *__restrict__ logz_total, int total_slot,
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
   uint32_t *ring = (uint32_t *)(gth + plan.v4);
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
-  constexpr bool has_extra = EXTRA == 1 || EXTRA == 2;  // (3: no extras, but the weight waves write the label weights)
+  constexpr bool has_extra = EXTRA != 0;
+  static_assert(!TW || (NT == 1024 && !FUSED), "tile waves: the one-lattice-per-CU flavour");
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // even waves work for the beta sweep, odd waves for alpha: waves 0 / 1 sweep, 2 / 3 decode,
   // 6 / 7 load (waves i, i+4, ... share a SIMD: the busy-polling loaders sit with the decoders,
@@ -146,7 +151,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   const int my_tiles = bwd_side ? m.bwd_tiles : m.fwd_tiles;
   const int my_u = bwd_side ? m.bwd_u : m.fwd_u;
   const bool my_wide = (bwd_side ? m.bwd_wide : m.fwd_wide) != 0;
-  uint32_t *my_ring = bwd_side ? ring : ring + LdsPlan::sweep_words(R, RS, EXTRA);
+  uint32_t *my_ring = bwd_side ? ring : ring + (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA));
+  const bool tw_v2 = TW && !my_wide;  // (the decoded-tile format of tile_sweep2: programs with narrow groups)
   uint32_t *my_raw = my_ring + (size_t)R * kSlotWords;
   // NT = 1024: the workgroup has the CU to itself: waves 4 / 5 load for the decoders (deep
   // staging ring); otherwise two workgroups share a CU and the decoders load for themselves
@@ -159,18 +165,25 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
 #endif
   // extras waves per sweep, the first of them (tuning: NFST_XW_MODE 1 = only the waves on the decoders' SIMDs, 2 = only
   // those on the sweep waves' SIMDs)
-  constexpr int kNE = (NT == 1024 && NFST_XW_MODE == 0) ? 4 : 2, kFirstX = NT == 1024 ? 8 : 4;
-  const bool x_wave = EXTRA != 0 && wv >= kFirstX && (NT != 1024 || NFST_XW_MODE == 0 || ((wv >> 1) & 1) == (NFST_XW_MODE == 1 ? 1 : 0));
-  const int x_index = (NT == 1024 && NFST_XW_MODE != 0) ? (wv - kFirstX) >> 2 : (wv - kFirstX) >> 1;
+  constexpr int kNE = (TW || (NT == 1024 && NFST_XW_MODE == 0)) ? 4 : 2, kFirstX = NT == 1024 ? 8 : 4;
+#ifndef NFST_TW_PLACE
+#define NFST_TW_PLACE 1
+#endif
+  // tile waves: 1 = waves 2 .. 9 (two per SIMD: one SIMD cannot issue a whole sweep's decoding -- ~100 slots per
+  // tile -- at the sweep's pace); 0 = the eight waves of SIMDs 2 and 3
+  const bool x_wave = TW ? (NFST_TW_PLACE == 1 ? (wv >= 2 && wv < 10) : (wv & 2) != 0)
+                         : EXTRA != 0 && wv >= kFirstX && (NT != 1024 || NFST_XW_MODE == 0 || ((wv >> 1) & 1) == (NFST_XW_MODE == 1 ? 1 : 0));
+  const int x_index = TW ? (NFST_TW_PLACE == 1 ? (wv - 2) >> 1 : wv >> 2) : (NT == 1024 && NFST_XW_MODE != 0) ? (wv - kFirstX) >> 2 : (wv - kFirstX) >> 1;
   if (FUSED) {
     if (wv < 2) FusedSweep<false>::start(my_prog, my_tiles, lane);  // (start() does not depend on WIDE)
+  } else if (TW) {  // (the tile waves start below)
   } else if (kSelf) {
     if (wv == 2 || wv == 3) self_start<kAhead>(my_u, my_prog, my_tiles, my_raw, lane);
   } else if (wv == 6 || wv == 7) {
     loader_start(my_u, my_prog, my_tiles, my_raw, RS, lane);
   }
   // extras waves: the slot -> arc maps of their first tiles go in flight now, the first gathers before the barrier
-  WeightWave<8, kNE, EXTRA % 3> xw8;
+  WeightWave<8, kNE, EXTRA, TW> xw8;
   if (x_wave && my_u == 8) xw8.start_maps(my_prog, my_perm, my_tiles, ex, x_index, lane);
   for (int i = tid; i < m.n_rows; i += NT) {
     alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   if (x_wave && my_u == 8) xw8.start_gathers(lane);
   __syncthreads();
-  int *flags = (int *)(ring + 2 * LdsPlan::sweep_words(R, RS, EXTRA));
+  int *flags = (int *)(ring + 2 * (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA)));
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     alpha[0] = make_float2(0.5f, __int_as_float(1));
@@ -222,8 +235,18 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       else FusedSweep<false>::run(my_prog, my_tiles, bwd_side ? beta : alpha, th, trash, lane);
     }
   } else if (x_wave) {
-    run_weights<kNE, EXTRA % 3>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th, lane);
-    if (kPre > 0 && want_post) preload_arcs();
+    run_weights<kNE, EXTRA, TW>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th,
+                                bwd_side ? beta : alpha, tw_v2, lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 512) + lane * 8, lane);
+    if (kPre > 0 && want_post && tid >= kSweepThreads) preload_arcs();
+  } else if (TW) {
+    if (wv < 2) {
+      int *fl = bwd_side ? flags : flags + kSweepFlags;
+      __builtin_amdgcn_s_setprio(3);  // (the chain: 45.8 -> 44.3 us at 256 lattices)
+      // (every program is compact: four slots per lane)
+      if (tw_v2) tile_sweep2<4, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
+      else tile_sweep<4, true, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
+      __builtin_amdgcn_s_setprio(0);
+    }
   } else if (wv < 4 || (!kSelf && (wv == 6 || wv == 7))) {
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog,
                      my_tiles, my_ring, R, bwd_side ? flags : flags + kSweepFlags, bwd_side ? beta : alpha, th, lane);

@@ -188,12 +188,21 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   // equal at 512; with one lattice per CU the three-wave pipeline is 10 % faster (46.8 against 51.8 us).
   const bool fused = !extra && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && lat->n_lattices > cus &&
                      !(no_fused && no_fused[0] == '1');
+  // one lattice per CU: tile waves instead of loader + decoder (NFST_TW=0: the three-wave pipeline, for A/B runs)
+  const char *tw_env = getenv("NFST_TW");
+  bool tw = false;
   if (fused) cfg = {0, 0, lat->n_lattices > cus};
   else if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
+  else if (!cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && !(tw_env && tw_env[0] == '0')) {
+    tw = true;  // no staging ring; ring slots of kSlotWords2 words
+    const int64_t slot = (int64_t)kSlotWords2 * 4 * 2;
+    const int64_t r = (kMaxLds - lds_reserve() - plan.fb_bytes(0, 0, extra)) / slot;
+    cfg = {(int)(r > kMaxRing ? kMaxRing : r), 0, false};
+  }
   if (extra && (((uintptr_t)lat->fwd_perm | (uintptr_t)lat->bwd_perm | (uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 15))
     return NFST_ERR_ARG;  // (maps and extras are read 16 bytes at a time)
   const int R = cfg.R, RS = cfg.RS;
-  const int64_t lds = plan.fb_bytes(R, RS, extra);
+  const int64_t lds = tw ? plan.fb_bytes(0, 0, extra) + (int64_t)R * kSlotWords2 * 4 * 2 : plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
     if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
@@ -201,6 +210,13 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
                        (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, logz_total,    \
                        (int)total_slot, posterior,                                                      \
                        grad_theta, (float2 *)beta_me);                                                  \
+  }
+#define NFST_LAUNCH_TW(EX)                                                                                 \
+  {                                                                                                     \
+    if ((rc = set_lds(k_forward_backward<1024, EX, false, true>, lds))) return rc;                      \
+    hipLaunchKernelGGL((k_forward_backward<1024, EX, false, true>), dim3(lat->n_lattices), dim3(1024), (size_t)lds, \
+                       (hipStream_t)stream, *lat, *scores, R, RS, logalpha, logbeta, logz64, logz32, logz_total,    \
+                       (int)total_slot, posterior, grad_theta, (float2 *)beta_me);                      \
   }
 #define NFST_LAUNCH_FUSED(NT)                                                                            \
   {                                                                                                     \
@@ -217,17 +233,17 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     // fused sweep's 32 AGPRs, and it then spills into AGPRs -- into the ones the sweep stages tiles in)
     if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FUSED(512)
     else NFST_LAUNCH_FUSED(256)
+  } else if (!cfg.self && tw) {
+    if (both) NFST_LAUNCH_TW(2) else if (extra) NFST_LAUNCH_TW(1) else NFST_LAUNCH_TW(0)
   } else if (!cfg.self) {
-    // without extras the weight waves still write the label weights (the decoder is lighter: 46.6 -> 45.5 us at 256
-    // lattices, 130.6 -> 126.4 us at 551 levels; profiles/r02_ab_ww.txt); NFST_WW=0 keeps them in the decoder (A/B runs)
-    const char *ww = getenv("NFST_WW");
-    if (both) NFST_LAUNCH_FB(1024, 2) else if (extra) NFST_LAUNCH_FB(1024, 1) else if (!(ww && ww[0] == '0')) NFST_LAUNCH_FB(1024, 3) else NFST_LAUNCH_FB(1024, 0)
+    if (both) NFST_LAUNCH_FB(1024, 2) else if (extra) NFST_LAUNCH_FB(1024, 1) else NFST_LAUNCH_FB(1024, 0)
   }
   else if (both) NFST_LAUNCH_FB(512, 2)  // (the weight waves are waves 4 .. 7)
   else if (extra) NFST_LAUNCH_FB(512, 1)
   else if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FB(512, 0)
   else NFST_LAUNCH_FB(256, 0)
 #undef NFST_LAUNCH_FB
+#undef NFST_LAUNCH_TW
 #undef NFST_LAUNCH_FUSED
   return hip_status(hipGetLastError());
 }

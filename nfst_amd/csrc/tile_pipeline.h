@@ -39,6 +39,7 @@
 constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSlotsShared = kDmaAheadShared + 1;
 constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
+constexpr int kSlotWords2 = 1024;               // ring slot of the tile-wave pipeline: 64 lanes x 64 bytes
 // program format code (meta word, bits 0..7): 1, 2, 4 = slots per lane with 32-bit records and a
 // separate control block; 8 = the compact tile: four slots per lane, 16 bytes per lane = control
 // word + four 24-bit records (state 13 bits | label 11 bits)
@@ -698,12 +699,19 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 // and caller scores): hipcc keeps counted s_waitcnt only where no branch lies between a load and its use.
 // Measured at 256 lattices: gathering both arrays when only one exists doubled the vector-L1 lookups
 // (64 per gather instruction) and slowed the tile stream of the loaders by a third.
-template <int F, int NE, int XM>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2)
+#ifndef NFST_X_NAP
+#define NFST_X_NAP 12
+#endif
+template <int F, int NE, int XM, bool FULL>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2)
 struct WeightWave {
-  static constexpr bool BOTH = XM == 2;
+  // FULL: the wave decodes its tiles completely -- control words and operand addresses as well -- straight
+  // from HBM into the decoded ring: no loader, no staging ring, no decoder wave (tile waves of the
+  // one-lattice-per-CU kernels); otherwise a decoder wave writes those and waits for this wave's flag.
   static constexpr int U = fmt_u(F);
-  struct P { int a[U]; uint32_t lab8[U]; };
-  struct G { float w[U], s[BOTH ? U : 1]; uint32_t valid; uint32_t lab8[U]; };
+  static constexpr bool BOTH = XM == 2;
+  static constexpr int RW = F == 8 ? 4 : (FULL ? 1 : 0) + U;  // raw words of a tile per lane
+  struct P { int a[XM != 0 ? U : 1]; uint32_t raw[RW]; };
+  struct G { float w[XM != 0 ? U : 1], s[BOTH ? U : 1]; uint32_t valid; uint32_t raw[RW]; };
   P p0, p1, p2;
   G g0, g1, g2;
   const float *bw, *bs;
@@ -713,52 +721,66 @@ struct WeightWave {
 
   __device__ __forceinline__ P ld_tile(int i, int lane) const {
     P p;
-    const int t = min(ei + i * NE, last);
+    const int t = ei + min(i, max(n_mine - 1, 0)) * NE;  // past this wave's last tile: that tile again
     const int32_t *q = perm + (size_t)t * (64 * U) + lane * U;
     const uint32_t *g = prog_words + (size_t)t * fmt_words(F);
-    if (XM == 0) {
-#pragma unroll
-      for (int j = 0; j < U; ++j) p.a[j] = -1;
-    }
+    if (XM == 0) p.a[0] = -1;
     if (U == 4) {
       if (XM != 0) {
         const int4 v = *reinterpret_cast<const int4 *>(q);
-        p.a[0] = v.x; p.a[1 % U] = v.y; p.a[2 % U] = v.z; p.a[3 % U] = v.w;
+        p.a[0] = v.x; p.a[XM != 0 ? 1 : 0] = v.y; p.a[XM != 0 ? 2 : 0] = v.z; p.a[XM != 0 ? 3 : 0] = v.w;
       }
       const uint4 x = *reinterpret_cast<const uint4 *>(g + (F == 8 ? 0 : 64) + lane * 4);
-      if (F == 8) {
-        const uint32_t r[4] = {x.y, __builtin_amdgcn_alignbit(x.z, x.y, 24), __builtin_amdgcn_alignbit(x.w, x.z, 16), x.w >> 8};
-#pragma unroll
-        for (int j = 0; j < U; ++j) p.lab8[j] = (r[j % 4] >> 10) & 0x3ff8u;
-      } else {
-        const uint32_t r[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int j = 0; j < U; ++j) p.lab8[j] = (r[j % 4] >> 16) << 3;
-      }
+      constexpr int o = (F != 8 && FULL) ? 1 : 0;
+      p.raw[o] = x.x; p.raw[o + 1] = x.y; p.raw[o + 2] = x.z; p.raw[o + 3] = x.w;
     } else if (U == 2) {
       if (XM != 0) {
         const int2 v = *reinterpret_cast<const int2 *>(q);
-        p.a[0] = v.x; p.a[1 % U] = v.y;
+        p.a[0] = v.x; p.a[XM != 0 ? 1 : 0] = v.y;
       }
       const uint2 x = *reinterpret_cast<const uint2 *>(g + 64 + lane * 2);
-      p.lab8[0] = (x.x >> 16) << 3; p.lab8[1 % U] = (x.y >> 16) << 3;
+      constexpr int o = FULL ? 1 : 0;
+      p.raw[o] = x.x; p.raw[o + 1] = x.y;
     } else {
       if (XM != 0) p.a[0] = q[0];
-      p.lab8[0] = (g[64 + lane] >> 16) << 3;
+      p.raw[FULL ? 1 : 0] = g[64 + lane];
     }
+    if (F != 8 && FULL) p.raw[0] = g[lane];  // the control word
     return p;
+  }
+  // raw words -> control word, 8 x operand state, 8 x label
+  __device__ __forceinline__ static void unpack(const uint32_t (&raw)[RW], uint32_t &ctl, uint32_t (&opoff)[U], uint32_t (&lab8)[U]) {
+    if (F == 8) {
+      ctl = raw[0];
+      const uint32_t r[4] = {raw[1], __builtin_amdgcn_alignbit(raw[2], raw[1], 24), __builtin_amdgcn_alignbit(raw[3], raw[2], 16),
+                             raw[3] >> 8};
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        opoff[j] = (r[j % 4] << 3) & 0xfff8u;
+        lab8[j] = (r[j % 4] >> 10) & 0x3ff8u;
+      }
+    } else {
+      ctl = FULL ? raw[0] : 0u;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t rc = raw[(FULL ? 1 : 0) + j];
+        opoff[j] = rc & 0xffffu;
+        lab8[j] = (rc >> 16) << 3;
+      }
+    }
   }
   __device__ __forceinline__ G issue(const P &p) const {
     G g;
     g.valid = 0;
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
+    for (int j = 0; j < (XM != 0 ? U : 0); ++j) {
       const int a = max(p.a[j], 0);
-      g.w[j] = XM != 0 ? bw[a] : 0.0f;
+      g.w[j] = bw[a];
       if (BOTH) g.s[j] = bs[a];
       g.valid |= (p.a[j] >= 0 ? 1u : 0u) << j;
-      g.lab8[j] = p.lab8[j];
     }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) g.raw[j] = p.raw[j];
     return g;
   }
   // kernel entry (right behind the meta record): the records and maps of this wave's first tiles are in
@@ -778,31 +800,70 @@ struct WeightWave {
     p0 = ld_tile(3, lane);
     g1 = issue(p1);
   }
-  __device__ __forceinline__ void run(uint32_t *ring, int R, const int *prog, int *xland, const float2 *th_, int lane) {
-    if (n_mine <= 0) return;
-    constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;
-    const uint32_t ring_base = lds_addr(ring), prog_a = lds_addr(prog), xl_a = lds_addr(xland) + (uint32_t)ei * 4;
-    const uint32_t th_base = lds_addr(th_);
+  // v2 (FULL, four slots per lane, narrow groups): the decoded tile of tile_sweep2 -- per lane the store address
+  // (the state's value for a leader lane, 8 bytes of trash otherwise) and the three 0 / 1 stage multipliers of the
+  // segmented sum instead of the control word.  Tile waves use ring slots of kSlotWords2 words for every format.
+  __device__ __forceinline__ void run(uint32_t *ring, int R, const int *prog, int *xland, const float2 *th_, const float2 *val, bool v2,
+                                      uint32_t trash, int lane) {
+    const uint32_t xl_a = lds_addr(xland) + (uint32_t)ei * 4;
+    if (n_mine <= 0) {
+      if (FULL) *(volatile lds_u32 *)(uintptr_t)xl_a = 0x7fffffffu;  // "every tile of mine is there" (there is none)
+      return;
+    }
+    constexpr uint32_t SB = FULL ? kSlotWords2 * 4 : 64 * (1 + 3 * U) * 4;
+    const uint32_t ring_base = lds_addr(ring), prog_a = lds_addr(prog);
+    const uint32_t th_base = lds_addr(th_), val_base = lds_addr(val);
     int prog_seen = 0;
     auto process = [&](int i, const G &g) {
-      const int t = ei + i * NE;
+      const int t = ei + min(i, n_mine - 1) * NE;
+      uint32_t ctl, opoff[U], lab8[U];
+      unpack(g.raw, ctl, opoff, lab8);
       v2f tw[U];
 #pragma unroll
-      for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + g.lab8[j]);
+      for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + lab8[j]);
       v2f o[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         if (XM == 0) { o[j] = tw[j]; continue; }
-        const float xs = BOTH ? g.w[j] + g.s[BOTH ? j : 0] : g.w[j];
+        const float xs = BOTH ? g.w[XM != 0 ? j : 0] + g.s[BOTH ? j : 0] : g.w[XM != 0 ? j : 0];
         const ME x = exp_split_nb(((g.valid >> j) & 1u) ? xs : 0.0f);
         o[j] = v2f{tw[j].x * x.m, __int_as_float(__float_as_int(tw[j].y) + x.e)};
       }
       while (__builtin_expect(prog_seen < t - R + 1, 0)) {  // the slot's previous tile is consumed
         prog_seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)prog_a);
-        if (prog_seen < t - R + 1) __builtin_amdgcn_s_sleep(2);
+        // (a blocked wave has its tile ready and the sweep is R - NE tiles behind: long naps, few issue slots)
+        if (prog_seen < t - R + 1) __builtin_amdgcn_s_sleep(NFST_X_NAP);
       }
       asm volatile("" ::: "memory");
       const uint32_t sb = ring_base + (uint32_t)(t % R) * SB;
+      if (FULL && v2) {
+        const int gl = (int)((ctl >> 20) & 7u);
+        const uint32_t dst = ((int)ctl < 0) ? (ctl & 0xffffu) + val_base : trash;
+        *(lds_v4u *)(uintptr_t)(sb + lane * 16) = v4u{dst, gl > 0 ? 0x3f800000u : 0u, gl > 1 ? 0x3f800000u : 0u, gl > 2 ? 0x3f800000u : 0u};
+        if (U == 4) {
+          *(lds_v4u *)(uintptr_t)(sb + 1024 + lane * 16) = v4u{opoff[0] + val_base, opoff[1 % U] + val_base, opoff[2 % U] + val_base, opoff[3 % U] + val_base};
+          *(lds_v4f *)(uintptr_t)(sb + 2048 + lane * 16) = v4f{o[0].x, o[0].y, o[1 % U].x, o[1 % U].y};
+          *(lds_v4f *)(uintptr_t)(sb + 3072 + lane * 16) = v4f{o[2 % U].x, o[2 % U].y, o[3 % U].x, o[3 % U].y};
+        } else if (U == 2) {
+          *(lds_v2u *)(uintptr_t)(sb + 1024 + lane * 8) = v2u{opoff[0] + val_base, opoff[1 % U] + val_base};
+          *(lds_v4f *)(uintptr_t)(sb + 2048 + lane * 16) = v4f{o[0].x, o[0].y, o[1 % U].x, o[1 % U].y};
+        } else {
+          *(lds_u32 *)(uintptr_t)(sb + 1024 + lane * 4) = opoff[0] + val_base;
+          *(lds_v2f *)(uintptr_t)(sb + 2048 + lane * 8) = o[0];
+        }
+        asm volatile("" ::: "memory");
+        *(volatile lds_u32 *)(uintptr_t)xl_a = (uint32_t)(t + 1);
+        return;
+      }
+      if (FULL) {
+        uint32_t oa[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) oa[j] = opoff[j] + val_base;
+        *(lds_u32 *)(uintptr_t)(sb + lane * 4) = ctl + val_base;
+        if (U == 4) *(lds_v4u *)(uintptr_t)(sb + 256 + lane * 16) = v4u{oa[0], oa[1 % U], oa[2 % U], oa[3 % U]};
+        else if (U == 2) *(lds_v2u *)(uintptr_t)(sb + 256 + lane * 8) = v2u{oa[0], oa[1 % U]};
+        else *(lds_u32 *)(uintptr_t)(sb + 256 + lane * 4) = oa[0];
+      }
       if (U == 4) {
         *(lds_v4f *)(uintptr_t)(sb + 256 + 1024 + lane * 16) = v4f{o[0].x, o[0].y, o[1 % U].x, o[1 % U].y};
         *(lds_v4f *)(uintptr_t)(sb + 256 + 2048 + lane * 16) = v4f{o[2 % U].x, o[2 % U].y, o[3 % U].x, o[3 % U].y};
@@ -821,13 +882,17 @@ struct WeightWave {
     GN = issue(PU);                  \
     PL = ld_tile(i + 4, lane);       \
     process(i, GC);
-    for (int i0 = 0; i0 < n_mine; i0 += 3) {
-      int i = i0;
-      NFST_X_STEP(p2, g2, p1, g0) if (++i >= n_mine) break;
-      NFST_X_STEP(p0, g0, p2, g1) if (++i >= n_mine) break;
-      NFST_X_STEP(p1, g1, p0, g2)
+    // (no exit inside a trip: past its last tile the wave writes that tile again -- same slot, same words --, which
+    // keeps the loop a single block per trip; with exits in between hipcc rotated registers through copies that
+    // wait for the loads just issued)
+    for (int i = 0; i < n_mine; i += 3) {
+      NFST_X_STEP(p2, g2, p1, g0) ++i;
+      NFST_X_STEP(p0, g0, p2, g1) ++i;
+      NFST_X_STEP(p1, g1, p0, g2) i -= 2;
     }
 #undef NFST_X_STEP
+    // every tile of this wave is there: a sweep that looks one tile past the end of its program never waits
+    if (FULL) *(volatile lds_u32 *)(uintptr_t)xl_a = 0x7fffffffu;
   }
 };
 
@@ -866,16 +931,20 @@ __device__ __forceinline__ void dec_fetch(uint32_t sb, int lane, TileDec<U> &d) 
 // straight-line code.  It starts with the operand gathers of its tile, fetches the next
 // decoded tile and prepares the stage masks in their shadow, and ends by moving the next
 // tile's wave-uniform flags to a scalar register.
-template <int U, bool WIDE>
+// NEF = 0: one producer (the decoder wave) counts decoded tiles in `land`; NEF > 0 (a power of two): NEF
+// tile waves, wave k decodes tiles k, k + NEF, ... and stores tile + 1 in land[k]
+template <int U, bool WIDE, int NEF = 0>
 __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land,
                                            int lane) {
   if (n_tiles <= 0) return;
-  constexpr uint32_t SB = 64 * (1 + 3 * U) * 4;  // bytes per ring slot
+  constexpr uint32_t SB = NEF > 0 ? kSlotWords2 * 4 : 64 * (1 + 3 * U) * 4;  // bytes per ring slot
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
   int landed = 0;  // wave-uniform copy of the decoder's counter, refreshed only when it runs out
-  auto wait_landed = [&](int need) {
+  auto wait_landed = [&](int need) {  // tiles 0 .. need-1 are decoded (NEF: tile need-1 is)
+    if (NEF > 0) landed = 0;
+    const int *flag = NEF > 0 ? land + ((need - 1) & (NEF - 1)) : land;
     while (__builtin_expect(landed < need, 0)) {
-      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(land));
+      landed = __builtin_amdgcn_readfirstlane(lds_flag_load(flag));
       if (landed < need) __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
@@ -896,10 +965,14 @@ __device__ __forceinline__ void tile_sweep(int n_tiles, const uint32_t *ring, in
     sb = (sb + SB == ring_end) ? ring_base : sb + SB;
     // the decoder's counter was read (LDS) during the previous iteration: in the common case the
     // check costs no LDS round trip
-    landed = max(landed, __builtin_amdgcn_readfirstlane(land_peek));
-    wait_landed(min(T + 2, n_tiles));
+    if (NEF > 0) {  // the flag of tile T+1's wave was read during the previous iteration
+      if (T + 1 < n_tiles && __builtin_amdgcn_readfirstlane(land_peek) < T + 2) wait_landed(T + 2);
+    } else {
+      landed = max(landed, __builtin_amdgcn_readfirstlane(land_peek));
+      wait_landed(min(T + 2, n_tiles));
+    }
     dec_fetch<U>(sb, lane, nxt);
-    land_peek = lds_flag_load(land);
+    land_peek = lds_flag_load(NEF > 0 ? land + ((T + 2) & (NEF - 1)) : land);
     asm volatile("" ::: "memory");
     // --- what only needs the tile's control word: stage masks (lanes whose state owns
     // more than 2^s lanes), leader lanes, store address
@@ -996,31 +1069,158 @@ __device__ __forceinline__ void run_sweep(int role, int U, bool wide, uint32_t *
   }
 }
 
+// ---- the sweep wave of the tile-wave pipeline, four slots per lane, narrow groups ---------------------
+// A single wave executes in order: every instruction of its loop lies on the level-to-level chain, the
+// bookkeeping as much as the arithmetic (measured: ~100 issue slots per tile in tile_sweep, ~4.3 cycles
+// each, plus one exposed LDS round trip).  Here everything that does not depend on DP values was moved to the
+// tile waves (store address incl. the leader select, the stage multipliers, no end-of-program tests: a
+// finished tile wave publishes "infinity"), and the segmented sum is three v_fmac_f32_dpp on terms
+// aligned to a stale wave-uniform exponent (tile_math): ~60 issue slots per tile.
+template <int U>
+struct Dec2 {
+  uint32_t dst;
+  float k0, k1, k2;
+  uint32_t opa[U];
+  v2f tw[U];
+};
+template <int U>
+__device__ __forceinline__ void dec2_fetch(uint32_t sb, int lane, Dec2<U> &d) {
+  const v4u h = *(const lds_v4u *)(uintptr_t)(sb + lane * 16);
+  d.dst = h.x; d.k0 = __uint_as_float(h.y); d.k1 = __uint_as_float(h.z); d.k2 = __uint_as_float(h.w);
+  if (U == 4) {
+    const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 1024 + lane * 16);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 2048 + lane * 16);
+    const v4f q = *(const lds_v4f *)(uintptr_t)(sb + 3072 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y; d.opa[2 % U] = a.z; d.opa[3 % U] = a.w;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w}; d.tw[2 % U] = v2f{q.x, q.y}; d.tw[3 % U] = v2f{q.z, q.w};
+  } else if (U == 2) {
+    const v2u a = *(const lds_v2u *)(uintptr_t)(sb + 1024 + lane * 8);
+    const v4f p = *(const lds_v4f *)(uintptr_t)(sb + 2048 + lane * 16);
+    d.opa[0] = a.x; d.opa[1 % U] = a.y;
+    d.tw[0] = v2f{p.x, p.y}; d.tw[1 % U] = v2f{p.z, p.w};
+  } else {
+    d.opa[0] = *(const lds_u32 *)(uintptr_t)(sb + 1024 + lane * 4);
+    d.tw[0] = *(const lds_v2f *)(uintptr_t)(sb + 2048 + lane * 8);
+  }
+}
+// tile_math with the per-lane constants precomputed (same arithmetic, same bits)
+template <int U>
+__device__ __forceinline__ void tile_math2(const v2f (&tw)[U], const v2f (&vv)[U], const Dec2<U> &c, int &ref) {
+  const int nref = -ref;
+  float mt[U];
+  int d[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    mt[j] = tw[j].x * vv[j].x;
+    d[j] = __float_as_int(tw[j].y) + __float_as_int(vv[j].y) + nref;
+  }
+  int dmax = d[0];
+#pragma unroll
+  for (int j = 1; j < U; ++j) dmax = max(dmax, d[j]);
+  float M = ldexpf(mt[0], d[0]);
+#pragma unroll
+  for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j]);
+  constexpr int kZeroish = -(1 << 27);
+  const bool bad = ((uint32_t)(dmax + 64) > 128u) & (dmax > kZeroish);
+  int E = ref;
+  const int e0 = __builtin_amdgcn_readfirstlane(dmax);
+  const int ref_old = ref;
+  ref = (e0 > kZeroish) ? e0 + ref_old : ref_old;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+    M = ldexpf(mt[0], d[0] - dmax);
+#pragma unroll
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j] - dmax);
+    E = dmax + ref_old;
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(c.k0 != 0.0f), m1 = __builtin_amdgcn_ballot_w64(c.k1 != 0.0f),
+                   m2 = __builtin_amdgcn_ballot_w64(c.k2 != 0.0f);
+    seg_reduce_exec<3>(M, E, m0, m1, m2);
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"  // (a DPP read needs two wait states after the vector write of its source: the compiler does not look into this block)
+        "v_fmac_f32_dpp %[m], %[m], %[k0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %[m], %[m], %[k1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %[m], %[m], %[k2] row_half_mirror row_mask:0xf bank_mask:0xf"
+        : [m] "+v"(M)
+        : [k0] "v"(c.k0), [k1] "v"(c.k1), [k2] "v"(c.k2));
+    E = (M == 0.0f) ? kEZero : E;
+  }
+  const float2 r = me_pack(M, E);
+  *(lds_v2f *)(uintptr_t)c.dst = v2f{r.x, r.y};
+}
+
+template <int U, int NEF>
+__device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land, int lane) {
+  if (n_tiles <= 0) return;
+  constexpr uint32_t SB = kSlotWords2 * 4;
+  const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+  const uint32_t land_a = lds_addr(land), prog_a = lds_addr(prog);
+  auto wait_tile = [&](int t) {  // tile t is decoded: its wave's flag holds more than t
+    const uint32_t fa = land_a + (uint32_t)(t & (NEF - 1)) * 4;
+    int seen;
+    do {
+      seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)fa);
+      if (seen <= t) __builtin_amdgcn_s_sleep(1);
+    } while (seen <= t);
+    asm volatile("" ::: "memory");
+  };
+  uint32_t sb = ring_base;
+  int peek = 0;  // the flag of tile T+1's wave as of the previous iteration
+  int ref = 0;
+  auto step = [&](int T, const Dec2<U> &cur, Dec2<U> &nxt) {
+    v2f vv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)cur.opa[j];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the operand gathers
+    sb = (sb + SB == ring_end) ? ring_base : sb + SB;
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(peek) <= T + 1, 0)) wait_tile(T + 1);
+    dec2_fetch<U>(sb, lane, nxt);
+    peek = (int)*(const volatile lds_u32 *)(uintptr_t)(land_a + (uint32_t)((T + 2) & (NEF - 1)) * 4);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    tile_math2<U>(cur.tw, vv, cur, ref);
+    *(volatile lds_u32 *)(uintptr_t)prog_a = (uint32_t)(T + 2);  // tiles 0 .. T+1 are consumed (their words are in registers)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  wait_tile(0);
+  Dec2<U> da, db;
+  dec2_fetch<U>(sb, lane, da);
+  asm volatile("" ::: "memory");
+  for (int T = 0; T < n_tiles; T += 2) {
+    step(T, da, db);
+    if (T + 1 >= n_tiles) break;
+    step(T + 1, db, da);
+  }
+}
+
 // a weight wave's part of a sweep: compact programs were started at kernel entry (x8), the rarer
 // formats start here
-template <int NE, int XM>
-__device__ __forceinline__ void run_weights(WeightWave<8, NE, XM> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
+template <int NE, int XM, bool FULL>
+__device__ __forceinline__ void run_weights(WeightWave<8, NE, XM, FULL> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
                                             int n_tiles, const Extra ex, int ei, uint32_t *ring, int R, int *flags,
-                                            const float2 *th, int lane) {
+                                            const float2 *th, const float2 *val, bool v2, uint32_t trash, int lane) {
   const int *prog = flags;
   int *xland = flags + 4;
-  if (F == 8) {
-    x8.run(ring, R, prog, xland, th, lane);
+  if (F == 8 || FULL) {  // (tile waves run all-compact batches only)
+    x8.run(ring, R, prog, xland, th, val, v2, trash, lane);
   } else if (F == 4) {
-    WeightWave<4, NE, XM> x;
+    WeightWave<4, NE, XM, FULL> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
-    x.run(ring, R, prog, xland, th, lane);
+    x.run(ring, R, prog, xland, th, val, v2, trash, lane);
   } else if (F == 2) {
-    WeightWave<2, NE, XM> x;
+    WeightWave<2, NE, XM, FULL> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
-    x.run(ring, R, prog, xland, th, lane);
+    x.run(ring, R, prog, xland, th, val, v2, trash, lane);
   } else {
-    WeightWave<1, NE, XM> x;
+    WeightWave<1, NE, XM, FULL> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
-    x.run(ring, R, prog, xland, th, lane);
+    x.run(ring, R, prog, xland, th, val, v2, trash, lane);
   }
 }
 
