@@ -197,7 +197,8 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     tw = true;  // no staging ring; ring slots of kSlotWords2 words
     const int64_t slot = (int64_t)kSlotWords2 * 4 * 2;
     const int64_t r = (kMaxLds - lds_reserve() - plan.fb_bytes(0, 0, extra)) / slot;
-    cfg = {(int)(r > kMaxRing ? kMaxRing : r), 0, false};
+    cfg = {(int)(r > kMaxRing ? kMaxRing : r) & ~3, 0, false};  // (tile_sweep2 takes four tiles per trip: a multiple of four slots)
+    if (cfg.R < 4) return NFST_ERR_LIMIT;
   }
   if (extra && (((uintptr_t)lat->fwd_perm | (uintptr_t)lat->bwd_perm | (uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 15))
     return NFST_ERR_ARG;  // (maps and extras are read 16 bytes at a time)

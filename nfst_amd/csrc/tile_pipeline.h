@@ -1150,50 +1150,109 @@ __device__ __forceinline__ void tile_math2(const v2f (&tw)[U], const v2f (&vv)[U
   *(lds_v2f *)(uintptr_t)c.dst = v2f{r.x, r.y};
 }
 
+// One tile of tile_sweep2: tile_math2's arithmetic (same bits) in an order that keeps the scalar uses of
+// vector results -- the test for the exact path, the next reference exponent -- away from the instructions that
+// produce them (a scalar use of a fresh vector result costs ~25 cycles): the fast result is computed
+// unconditionally and replaced in the rare tile that needs the exact path.
+template <int U>
+__device__ __forceinline__ void tile_math3(const Dec2<U> &c, const v2f (&vv)[U], int &ref) {
+  const int nref = -ref;
+  float mt[U];
+  int d[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    mt[j] = c.tw[j].x * vv[j].x;
+    d[j] = (__float_as_int(c.tw[j].y) + nref) + __float_as_int(vv[j].y);
+  }
+  int dmax = d[0];
+#pragma unroll
+  for (int j = 1; j < U; ++j) dmax = max(dmax, d[j]);
+  constexpr int kZeroish = -(1 << 27);
+  const uint64_t bad = __builtin_amdgcn_ballot_w64(((uint32_t)(dmax + 64) > 128u) & (dmax > kZeroish));
+  const int e0 = __builtin_amdgcn_readfirstlane(dmax);
+  const int ref_old = ref;
+  float M = ldexpf(mt[0], d[0]);
+#pragma unroll
+  for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j]);
+  asm volatile(
+      "s_nop 1\n\t"  // (a DPP read needs two wait states after the vector write of its source: the compiler does not look into this block)
+      "v_fmac_f32_dpp %[m], %[m], %[k0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %[m], %[m], %[k1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %[m], %[m], %[k2] row_half_mirror row_mask:0xf bank_mask:0xf"
+      : [m] "+v"(M)
+      : [k0] "v"(c.k0), [k1] "v"(c.k1), [k2] "v"(c.k2));
+  ref = (e0 > kZeroish) ? e0 + ref_old : ref_old;
+  int E = ref_old;
+  if (__builtin_expect(bad != 0, 0)) {
+    M = ldexpf(mt[0], d[0] - dmax);
+#pragma unroll
+    for (int j = 1; j < U; ++j) M += ldexpf(mt[j], d[j] - dmax);
+    E = dmax + ref_old;
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(c.k0 != 0.0f), m1 = __builtin_amdgcn_ballot_w64(c.k1 != 0.0f),
+                   m2 = __builtin_amdgcn_ballot_w64(c.k2 != 0.0f);
+    seg_reduce_exec<3>(M, E, m0, m1, m2);
+  }
+  // (mantissa, exponent): an exact zero keeps the exponent that never wins a maximum
+  int ex;
+  const float mant = frexpf(M, &ex);
+  const int eo = (M != 0.0f) ? max(E + ex, kEZero) : kEZero;
+  *(lds_v2f *)(uintptr_t)c.dst = v2f{mant, __int_as_float(eo)};
+}
+
+// Four tiles per trip (the ring holds a multiple of four slots, so a trip's slots are consecutive and the fetch
+// addresses are one base plus immediates; tile t's wave is t mod 4, so the four flags -- one 16-byte read -- are
+// checked once per trip for the four tiles the trip fetches; `prog` is published every other tile).
 template <int U, int NEF>
 __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land, int lane) {
+  static_assert(NEF == 4, "four tile waves per sweep");
   if (n_tiles <= 0) return;
   constexpr uint32_t SB = kSlotWords2 * 4;
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
   const uint32_t land_a = lds_addr(land), prog_a = lds_addr(prog);
-  auto wait_tile = [&](int t) {  // tile t is decoded: its wave's flag holds more than t
-    const uint32_t fa = land_a + (uint32_t)(t & (NEF - 1)) * 4;
-    int seen;
-    do {
-      seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)fa);
-      if (seen <= t) __builtin_amdgcn_s_sleep(1);
-    } while (seen <= t);
+  // min over the four tiles T+1 .. T+4 of (their wave's flag - their offset): all four are decoded iff it exceeds T
+  auto group_margin = [&]() {
+    const v4u f = *(const volatile lds_v4u *)(uintptr_t)land_a;
+    return min(min((int)f.y - 1, (int)f.z - 2), min((int)f.w - 3, (int)f.x - 4));
+  };
+  auto wait_group = [&](int T) {
+    while (__builtin_amdgcn_readfirstlane(group_margin()) <= T) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
   };
-  uint32_t sb = ring_base;
-  int peek = 0;  // the flag of tile T+1's wave as of the previous iteration
-  int ref = 0;
-  auto step = [&](int T, const Dec2<U> &cur, Dec2<U> &nxt) {
-    v2f vv[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)cur.opa[j];
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled in front of the operand gathers
-    sb = (sb + SB == ring_end) ? ring_base : sb + SB;
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane(peek) <= T + 1, 0)) wait_tile(T + 1);
-    dec2_fetch<U>(sb, lane, nxt);
-    peek = (int)*(const volatile lds_u32 *)(uintptr_t)(land_a + (uint32_t)((T + 2) & (NEF - 1)) * 4);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    tile_math2<U>(cur.tw, vv, cur, ref);
-    *(volatile lds_u32 *)(uintptr_t)prog_a = (uint32_t)(T + 2);  // tiles 0 .. T+1 are consumed (their words are in registers)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  wait_tile(0);
-  Dec2<U> da, db;
-  dec2_fetch<U>(sb, lane, da);
+  while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32 *)(uintptr_t)land_a) <= 0) __builtin_amdgcn_s_sleep(1);  // tile 0
   asm volatile("" ::: "memory");
-  for (int T = 0; T < n_tiles; T += 2) {
-    step(T, da, db);
-    if (T + 1 >= n_tiles) break;
-    step(T + 1, db, da);
+  uint32_t gbase = ring_base;  // slot of the trip's first tile
+  int margin = 0;              // group_margin() as of the previous trip's last tile (per-lane copy)
+  int ref = 0;
+  Dec2<U> da, db;
+  dec2_fetch<U>(gbase, lane, da);
+  asm volatile("" ::: "memory");
+  // tile T+K: `cur` in registers; fetches tile T+K+1 into `nxt`
+#define NFST_S2_STEP(K, CUR, NXT)                                                                          \
+  {                                                                                                       \
+    v2f vv[U];                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)CUR.opa[j];         \
+    asm volatile("" ::: "memory");                                                                        \
+    __builtin_amdgcn_sched_barrier(0); /* nothing is scheduled in front of the operand gathers */         \
+    if (K == 3) gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;                        \
+    dec2_fetch<U>(gbase + (K == 3 ? 0u : (K + 1) * SB), lane, NXT);                                       \
+    if (K == 3) margin = group_margin();                                                                  \
+    asm volatile("" ::: "memory");                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    tile_math3<U>(CUR, vv, ref);                                                                          \
+    if (K & 1) *(volatile lds_u32 *)(uintptr_t)prog_a = (uint32_t)(T + K + 2); /* tiles 0 .. T+K+1 are consumed */ \
+    asm volatile("" ::: "memory");                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
   }
+  for (int T = 0; T < n_tiles; T += 4) {
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin) <= T, 0)) wait_group(T);
+    NFST_S2_STEP(0, da, db) if (T + 1 >= n_tiles) break;
+    NFST_S2_STEP(1, db, da) if (T + 2 >= n_tiles) break;
+    NFST_S2_STEP(2, da, db) if (T + 3 >= n_tiles) break;
+    NFST_S2_STEP(3, db, da)
+  }
+#undef NFST_S2_STEP
 }
 
 // a weight wave's part of a sweep: compact programs were started at kernel entry (x8), the rarer
