@@ -249,12 +249,17 @@ void schedule(Lat &L, int vocab, const Opts &o) {
   // program by a cost model of the sweep kernel -- cycles per tile as measured on MI355X
   // (one wave): ~330 + 55 U, and ~450 more for a tile on the general
   // path; a program without wide tiles also saves the per-tile test for them.
+  // Round 2: where the labels fit the compact tile, four slots per lane always -- all-compact batches run
+  // the tile-wave / fused kernels, whose tile costs ~370 cycles whatever its fill (measured, 256 lattices
+  // of 2k states: 551 levels 131 -> 106 us, 277 levels 77 -> 59 us against the cost model's choice of U = 1, 2).
+  const bool compact_ok = vocab + 2 <= 2048 && !o.no_compact;
   auto pick = [&](bool backward, int &u_out, int &wide_out) {
     const int us[3] = {1, 2, 4};
     double best = 0.0;
     bool have = false;
     for (int q = 0; q < 3; ++q) {
       if ((o.slots_per_lane == 1 || o.slots_per_lane == 2 || o.slots_per_lane == 4) && us[q] != o.slots_per_lane) continue;
+      if (o.slots_per_lane == 0 && compact_ok && us[q] != 4) continue;
       for (int wide = 0; wide < 2; ++wide) {
         if ((o.group_mode == 1 && wide) || (o.group_mode == 2 && !wide)) continue;
         TileCount c;
@@ -272,9 +277,8 @@ void schedule(Lat &L, int vocab, const Opts &o) {
   pick(false, L.fwd_u, L.fwd_wide);
   L.fwd.clear(); L.bwd.clear(); L.fwd_perm.clear(); L.bwd_perm.clear();
   // programs with four slots per lane use the compact tile when the labels fit 11 bits
-  const bool fits = vocab + 2 <= 2048 && !o.no_compact;
-  L.bwd_compact = fits && L.bwd_u == 4;
-  L.fwd_compact = fits && L.fwd_u == 4;
+  L.bwd_compact = compact_ok && L.bwd_u == 4;
+  L.fwd_compact = compact_ok && L.fwd_u == 4;
   TileCount cb, cf;
   for (int t = 1; t <= D; ++t) {
     emit_level(by_height[t], L.bwd_u, L.bwd_wide ? 6 : 3, L.bwd_compact, null_label, n, out_of, dst_of, out_list, L.label, &L.bwd, &L.bwd_perm, cb);
