@@ -31,7 +31,8 @@ struct LdsPlan {
 // Wave 0 sweeps the by-source program from the sink, wave 1 decodes for it, wave 2 loads
 // for the decoder; with per-arc extras the last four (two) waves are the extras waves; every wave
 // helps with the initialisation and the outputs.
-template <int NT, int EXTRA>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both
+// TW (512 threads, all-compact batches): wave 0 sweeps (tile_sweep2), waves 1, 2, 3, 5 are its tile waves.
+template <int NT, int EXTRA, bool TW = false>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both
 __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, int RS, float *logbeta,
                                                  double *logz64, float *logz32, float2 *beta_me) {
   extern __shared__ float2 lds[];
@@ -53,28 +54,39 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   constexpr bool kSelf = NT != 512;
   constexpr int kAhead = kSelf ? kDmaAheadShared : kDmaAheadDeep;
   constexpr int kNE = kSelf ? 2 : 4, kFirstX = kSelf ? 2 : 4;  // extras waves: the last kNE waves of the block
-  if (kSelf) {
+  static_assert(!TW || NT == 512, "tile waves: the one-lattice-per-CU flavour");
+  if (TW) {  // (the tile waves start below)
+  } else if (kSelf) {
     if (wv == 1) self_start<kAhead>(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, raw, lane);
   } else if (wv == 2) {
     loader_start(m.bwd_u, lat.bwd_stream + m.bwd_off, m.bwd_tiles, raw, RS, lane);
   }
-  // extras waves: the slot -> arc maps of their first tiles go in flight now, the first gathers before the barrier
-  const bool x_wave = EXTRA != 0 && wv >= kFirstX;
-  WeightWave<8, kNE, EXTRA, false> xw8;
-  if (x_wave && m.bwd_u == 8) xw8.start_maps(lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, lane);
+  // weight / tile waves: the records and maps of their first tiles go in flight now, the first gathers before the barrier
+  const bool x_wave = TW ? (wv == 1 || wv == 2 || wv == 3 || wv == 5) : (EXTRA != 0 && wv >= kFirstX);
+  const int x_index = TW ? (wv < 4 ? wv - 1 : 3) : wv - kFirstX;
+  WeightWave<8, kNE, EXTRA, TW> xw8;
+  if (x_wave && m.bwd_u == 8) xw8.start_maps(lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, x_index, lane);
   for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
   if (x_wave && m.bwd_u == 8) xw8.start_gathers(lane);
   __syncthreads();
-  int *flags = (int *)(ring + LdsPlan::sweep_words(R, RS, EXTRA));
+  int *flags = (int *)(ring + (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA)));
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     for (int i = 0; i < kSweepFlags; ++i) flags[i] = 0;
   }
   __syncthreads();
+  const bool tw_v2 = TW && m.bwd_wide == 0;
   if (x_wave) {
-    run_weights<kNE, EXTRA, false>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, wv - kFirstX, ring, R, flags, th, beta,
-                                   false, 0u, lane);
+    run_weights<kNE, EXTRA, TW>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, x_index, ring, R, flags, th, beta,
+                                tw_v2, lds_addr(flags + kSweepFlags) + lane * 8, lane);
+  } else if constexpr (TW) {
+    if (wv == 0) {
+      __builtin_amdgcn_s_setprio(3);
+      if (tw_v2) tile_sweep2<4, kNE>(m.bwd_tiles, ring, R, flags, flags + 4, lane);
+      else tile_sweep<4, true, kNE>(m.bwd_tiles, ring, R, flags, flags + 4, lane);
+      __builtin_amdgcn_s_setprio(0);
+    }
   } else if (wv < (kSelf ? 2 : 3))
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off,
               m.bwd_tiles, ring, R, flags, beta, th, lane);

@@ -152,8 +152,23 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   RingCfg cfg;
   if (!ring_config(plan, false, extra, lat->n_lattices <= cu_count(), &cfg)) return NFST_ERR_LIMIT;
   if (extra && ((uintptr_t)lat->bwd_perm & 15)) return NFST_ERR_ARG;  // the extras waves read the slot -> arc map 16 bytes at a time
+  // one lattice per CU, all-compact: tile waves (NFST_TW=0: loader + decoder + sweep, for A/B runs)
+  const char *tw_env = getenv("NFST_TW");
+  const bool tw = !cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && !(tw_env && tw_env[0] == '0');
+  const int64_t tw_fixed = plan.bwd_bytes(0, 0, extra) + 512;  // + 64 x 8 bytes of trash for the non-leader lanes' stores
+  if (tw) {
+    const int64_t r = (kMaxLds - lds_reserve() - tw_fixed) / ((int64_t)kSlotWords2 * 4);
+    cfg = {(int)(r > kMaxRing ? kMaxRing : r) & ~3, 0, false};
+    if (cfg.R < 4) return NFST_ERR_LIMIT;
+  }
   const int R = cfg.R, RS = cfg.RS;
-  const int64_t lds = plan.bwd_bytes(R, RS, extra);
+  const int64_t lds = tw ? tw_fixed + (int64_t)R * kSlotWords2 * 4 : plan.bwd_bytes(R, RS, extra);
+#define NFST_LAUNCH_BWD_TW(EX)                                                                           \
+  {                                                                                                    \
+    if ((rc = set_lds(k_backward<512, EX, true>, lds))) return rc;                                     \
+    hipLaunchKernelGGL((k_backward<512, EX, true>), dim3(lat->n_lattices), dim3(512), (size_t)lds,     \
+                       (hipStream_t)stream, *lat, *scores, R, RS, logbeta, logz64, logz32, (float2 *)beta_me); \
+  }
 #define NFST_LAUNCH_BWD(NT, EX)                                                                          \
   {                                                                                                    \
     if ((rc = set_lds(k_backward<NT, EX>, lds))) return rc;                                            \
@@ -162,9 +177,11 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   }
   // 512 threads: loader + decoder + sweep (deep); 256 threads: self-loading decoder + sweep
   const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
-  if (!cfg.self) { if (both) NFST_LAUNCH_BWD(512, 2) else if (extra) NFST_LAUNCH_BWD(512, 1) else NFST_LAUNCH_BWD(512, 0) }
+  if (tw) { if (both) NFST_LAUNCH_BWD_TW(2) else if (extra) NFST_LAUNCH_BWD_TW(1) else NFST_LAUNCH_BWD_TW(0) }
+  else if (!cfg.self) { if (both) NFST_LAUNCH_BWD(512, 2) else if (extra) NFST_LAUNCH_BWD(512, 1) else NFST_LAUNCH_BWD(512, 0) }
   else { if (both) NFST_LAUNCH_BWD(256, 2) else if (extra) NFST_LAUNCH_BWD(256, 1) else NFST_LAUNCH_BWD(256, 0) }
 #undef NFST_LAUNCH_BWD
+#undef NFST_LAUNCH_BWD_TW
   return hip_status(hipGetLastError());
 }
 
