@@ -226,6 +226,19 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
   uint4 psd[kPre > 0 ? kPre : 1];
   uint2 plb[kPre > 0 ? kPre : 1];
+  float4 pxe[kPre > 0 ? kPre : 1];  // their per-arc extras (kernels with extras: 15.1 -> ... us of tail when fetched after the sweeps)
+  // the per-arc extras of 4 consecutive canonical arcs (16-byte loads: a is a multiple of 4)
+  auto extras4 = [&](int a) {
+    float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (has_extra) {
+      if (ex.arc_w) x = *reinterpret_cast<const float4 *>(ex.arc_w + a);
+      if (ex.arc_scores) {
+        const float4 y = *reinterpret_cast<const float4 *>(ex.arc_scores + a);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+    }
+    return x;
+  };
   auto preload_arcs = [&]() {
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
@@ -233,12 +246,13 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       if (a < v_end) {
         psd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
         plb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
+        if (has_extra) pxe[u] = extras4(a);
       }
     }
   };
-  // (an extras wave fetches its groups when its tiles are done: HBM misses in front of its gathers
-  // would hold them back -- a wave's loads complete in order)
-  if (kPre > 0 && tid >= kSweepThreads && want_post && !x_wave) preload_arcs();
+  // (in program order behind the sweeps' dispatch: the idle waves get there at once, a tile / weight / loader
+  // wave when its tiles are done -- HBM misses in front of its loads would hold them back, a wave's loads
+  // complete in order -- and the preloaded registers are not live across the pipeline code)
   // waves 0 / 1 run the beta / alpha sweeps, waves 2 / 3 decode and waves 6 / 7 load for them
   if constexpr (FUSED) {
     if (wv < 2) {
@@ -249,7 +263,6 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   } else if (x_wave) {
     run_weights<kNE, EXTRA, TW>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th,
                                 bwd_side ? beta : alpha, tw_v2, lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 512) + lane * 8, lane);
-    if (kPre > 0 && want_post && tid >= kSweepThreads) preload_arcs();
   } else if constexpr (TW) {
     if (wv < 2) {
       int *fl = bwd_side ? flags : flags + kSweepFlags;
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog,
                      my_tiles, my_ring, R, bwd_side ? flags : flags + kSweepFlags, bwd_side ? beta : alpha, th, lane);
   }
+  if (kPre > 0 && want_post && tid >= kSweepThreads) preload_arcs();
   __syncthreads();
   const float2 zme = beta[0];
   if (tid == 0) {
@@ -276,18 +290,6 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   }
   const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
   const int ez = __float_as_int(zme.y);
-  // the per-arc extras of 4 consecutive canonical arcs (16-byte loads: a is a multiple of 4)
-  auto extras4 = [&](int a) {
-    float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (has_extra) {
-      if (ex.arc_w) x = *reinterpret_cast<const float4 *>(ex.arc_w + a);
-      if (ex.arc_scores) {
-        const float4 y = *reinterpret_cast<const float4 *>(ex.arc_scores + a);
-        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-      }
-    }
-    return x;
-  };
   auto do_group = [&](const uint4 sd, const uint2 lb, int a, const float4 xe) {
     const float xv[4] = {xe.x, xe.y, xe.z, xe.w};
     const uint32_t sdv[4] = {sd.x, sd.y, sd.z, sd.w};
@@ -302,13 +304,10 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
   };
   if (kPre > 0 && tid >= kSweepThreads && want_post) {
-    float4 pxe[kPre > 0 ? kPre : 1];  // all extras of the preloaded groups are requested before the first is used
-#pragma unroll
-    for (int u = 0; u < kPre; ++u) pxe[u] = extras4(min(v_begin + 4 * (u * kHelpers + (tid - kSweepThreads)), max(v_end - 4, v_begin)));
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
       const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
-      if (a < v_end) do_group(psd[u], plb[u], a, pxe[u]);
+      if (a < v_end) do_group(psd[u], plb[u], a, has_extra ? pxe[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
   }
   // the row outputs: every thread (the sweep waves start here, the others come when their preloaded

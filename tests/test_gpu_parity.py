@@ -1037,3 +1037,44 @@ def test_beta_neural_grad_funnels(dev):
         assert np.max(np.abs(r.beta_hat.detach().cpu().numpy()[: l.n_rows] - bhat)) <= 3e-5
         for k in PARAMS:
             assert rec("neural_grad_rel_funnels", _rel(got[k], ref[k].reshape(np.shape(p[k])))) <= 1e-4, (opts, k)
+
+
+# ----------------------------------------------------------------------------- tile waves (one lattice per CU)
+def test_tile_waves_short_programs_and_flavour_bits(dev, monkeypatch):
+    """The tile-wave kernels (all-compact batches, at most one lattice per CU) on programs shorter than the
+    four tile waves of a sweep, programs of 1 .. 9 tiles, wide groups, table weights + caller scores, and
+    beside them the loader / decoder / sweep pipeline (NFST_TW=0): same bits for log Z, the row outputs and
+    the posteriors, oracle parity for both, beta-only sweep included."""
+    V = 40
+    lats = []
+    for n in (1, 2, 3, 4, 5, 7, 9, 13):  # chains of n levels: n tiles per direction
+        lats.append(synth._finish(n + 1, V, list(range(n)), [3 + (i % 30) for i in range(n)], list(range(1, n + 1))))
+    lats += [synth.layered_lattice(90 + i, n_states=30 + 25 * i, avg_degree=3.0 + i, vocab=V, width=1 + i, span=1 + i % 3, weighted=True)
+             for i in range(6)]
+    lats.append(synth.layered_lattice(97, n_states=300, avg_degree=12.0, vocab=V, width=24, span=2, max_degree=36, weighted=True))
+    theta = synth.label_scores(7, V)
+    th = torch.from_numpy(theta)
+    for weighted_ok, opts in ((False, dict()), (True, dict()), (True, dict(group_mode=2))):
+        import dataclasses
+        use = [l for l in lats if l.weight is None] if not weighted_ok else \
+            [l if l.weight is not None else dataclasses.replace(l, weight=np.zeros(l.n_arcs, np.float32)) for l in lats]
+        lat = LatticeBatch.from_synth(use, device=dev, **opts)
+        assert lat._h["reserved0"] & 1, "every program of this batch should be compact"
+        asc = np.random.default_rng(len(use)).normal(0.0, 0.4, size=lat.total_arcs).astype(np.float32)
+        for scores in (None, asc):
+            t = None if scores is None else torch.from_numpy(scores)
+            res = {}
+            for tw in ("1", "0"):
+                monkeypatch.setenv("NFST_TW", tw)
+                res[tw] = (ops.forward_backward(lat, th, arc_scores=t), ops.backward(lat, th, arc_scores=t))
+            monkeypatch.delenv("NFST_TW")
+            (fa, ba), (fb, bb) = res["1"], res["0"]
+            assert torch.equal(fa.logz64, fb.logz64) and torch.equal(fa.logalpha, fb.logalpha) and torch.equal(fa.logbeta, fb.logbeta)
+            assert torch.equal(ba.logz64, bb.logz64) and torch.equal(ba.logbeta, bb.logbeta)
+            assert float(torch.max(torch.abs(fa.posterior - fb.posterior))) <= 2e-7  # (the posterior pass is the same code)
+            for b, l in enumerate(use):
+                a0 = int(lat.arc_off[b])
+                o, _ = oracle_fb(l, theta, None if scores is None else scores[a0:a0 + l.n_arcs])
+                assert rec("tile_waves_logz", abs(float(fa.logz64[b]) - o["logZ"])) <= TOL, (weighted_ok, opts, scores is None, b, l.n_rows)
+                assert abs(float(ba.logz64[b]) - o["logZ"]) <= TOL
+                assert np.max(np.abs(fa.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
