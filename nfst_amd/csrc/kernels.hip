@@ -272,6 +272,26 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
   if (!best || !paths || !lengths || max_len <= 0) return NFST_ERR_ARG;
+  // all-compact batches: the tile-wave kernel (NFST_TW=0: one wave reading the program from global memory, for A/B runs)
+  const char *tw_env = getenv("NFST_TW");
+  const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
+  const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
+  const int64_t tw_fixed = VitLds(lat->max_rows, lat->vocab).fixed();
+  int64_t tw_r = (kMaxLds - tw_fixed) / ((int64_t)kSlotWords2 * 4);
+  tw_r = (tw_r > kMaxRing ? kMaxRing : tw_r) & ~(int64_t)3;
+  if ((lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tw_r >= 4 && !(tw_env && tw_env[0] == '0') &&
+      (!extra || (((uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 3) == 0) && ((uintptr_t)lat->bwd_perm & 15) == 0) {
+    const int64_t lds = tw_fixed + tw_r * kSlotWords2 * 4;
+#define NFST_LAUNCH_VIT(XM)                                                                                          \
+    {                                                                                                                \
+      if ((rc = set_lds(k_viterbi_tw<XM>, lds))) return rc;                                                          \
+      hipLaunchKernelGGL(k_viterbi_tw<XM>, dim3(lat->n_lattices), dim3(kVitTwThreads), (size_t)lds, (hipStream_t)stream, \
+                         *lat, *scores, (int)tw_r, best, paths, path_arcs, lengths, (int)max_len, (int)pad);        \
+    }
+    if (both) NFST_LAUNCH_VIT(2) else if (extra) NFST_LAUNCH_VIT(1) else NFST_LAUNCH_VIT(0)
+#undef NFST_LAUNCH_VIT
+    return hip_status(hipGetLastError());
+  }
   const int64_t lds = (int64_t)lat->max_rows * 12 + (int64_t)lat->vocab * 4 + 16;
   if ((rc = set_lds(k_viterbi, lds))) return rc;
   hipLaunchKernelGGL(k_viterbi, dim3(lat->n_lattices), dim3(kVitThreads), (size_t)lds, (hipStream_t)stream, *lat,

@@ -208,6 +208,298 @@ __global__ __launch_bounds__(kVitThreads) void k_viterbi(nfst_batch lat, nfst_sc
   }
 }
 
+// ------------------------------------------------------------------ Viterbi on tile waves
+// The same max-plus sweep on the tile-wave pipeline of the sum-product kernels (tile_pipeline.h; all-compact
+// batches): wave 0 sweeps, waves 1, 2, 3, 5 decode every fourth tile of the by-source program straight from HBM
+// into a ring of decoded tiles in LDS -- per lane the store address (a leader's state record, 16 bytes of trash
+// otherwise), the group size / largest group of the tile / which slots are unit-label records, four operand
+// record addresses, four arc scores (label score + per-arc extras; -inf for an empty slot, 0 for a unit record)
+// and the four canonical arcs.  A state's record in LDS is 16 bytes: best value, best arc, the record address
+// of the arc's other end (the trace-back is an LDS walk), so a leader stores one ds_write_b128.
+constexpr int kVitTwThreads = 512, kVitNE = 4;
+struct VitLds {
+  int rows, vocab;
+  __host__ __device__ VitLds(int r, int v) : rows(r), vocab(v) {}
+  // 16 B records | float label scores [V + 2] (null label: -inf, unit label: 0) | ring | flags | 64 x 16 B of trash
+  __host__ __device__ int64_t fixed() const { return (int64_t)rows * 16 + (int64_t)((vocab + 2 + 3) & ~3) * 4 + kSweepFlags * 4 + 1024; }
+};
+
+template <int XM>  // arrays of per-arc extras: 0, 1, 2
+struct VitWave {
+  struct P { int a[4]; uint32_t raw[4]; };
+  struct G { float w[XM != 0 ? 4 : 1], s[XM == 2 ? 4 : 1]; int a[4]; uint32_t raw[4]; };
+  P p0, p1, p2;
+  G g0, g1, g2;
+  const float *bw, *bs;
+  const int32_t *perm;
+  const uint32_t *prog_words;
+  int n_mine, ei;
+  __device__ __forceinline__ P ld_tile(int i, int lane) const {
+    P p;
+    const int t = ei + min(i, max(n_mine - 1, 0)) * kVitNE;  // past this wave's last tile: that tile again
+    const int4 v = *reinterpret_cast<const int4 *>(perm + (size_t)t * 256 + lane * 4);
+    p.a[0] = v.x; p.a[1] = v.y; p.a[2] = v.z; p.a[3] = v.w;
+    const uint4 x = *reinterpret_cast<const uint4 *>(prog_words + (size_t)t * 256 + lane * 4);
+    p.raw[0] = x.x; p.raw[1] = x.y; p.raw[2] = x.z; p.raw[3] = x.w;
+    return p;
+  }
+  __device__ __forceinline__ G issue(const P &p) const {
+    G g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a = max(p.a[j], 0);
+      if (XM != 0) g.w[j] = bw[a];
+      if (XM == 2) g.s[j] = bs[a];
+      g.a[j] = p.a[j];
+      g.raw[j] = p.raw[j];
+    }
+    return g;
+  }
+  __device__ __forceinline__ void start(const uint32_t *prog_, const int32_t *perm_, int n_tiles, const Extra ex, int ei_, int lane) {
+    perm = perm_; prog_words = prog_; ei = ei_;
+    n_mine = n_tiles > ei ? (n_tiles - ei + kVitNE - 1) / kVitNE : 0;
+    bw = ex.arc_w ? ex.arc_w : ex.arc_scores;
+    bs = ex.arc_scores;
+    if (n_mine <= 0) return;
+    p0 = ld_tile(0, lane); p1 = ld_tile(1, lane); p2 = ld_tile(2, lane);
+    g0 = issue(p0);
+    p0 = ld_tile(3, lane);
+    g1 = issue(p1);
+  }
+  __device__ __forceinline__ void run(uint32_t *ring, int R, const int *prog, int *xland, const float *tl, uint32_t rec_base,
+                                      uint32_t trash, int vocab, int lane) {
+    const uint32_t xl_a = lds_addr(xland) + (uint32_t)ei * 4;
+    if (n_mine <= 0) {
+      *(volatile lds_u32 *)(uintptr_t)xl_a = 0x7fffffffu;
+      return;
+    }
+    constexpr uint32_t SB = kSlotWords2 * 4;
+    const uint32_t ring_base = lds_addr(ring), prog_a = lds_addr(prog), tl_base = lds_addr(tl);
+    int prog_seen = 0;
+    auto process = [&](int i, const G &g) {
+      const int t = ei + min(i, n_mine - 1) * kVitNE;
+      const uint32_t ctl = g.raw[0];
+      const uint32_t r[4] = {g.raw[1], __builtin_amdgcn_alignbit(g.raw[2], g.raw[1], 24), __builtin_amdgcn_alignbit(g.raw[3], g.raw[2], 16),
+                             g.raw[3] >> 8};
+      uint32_t opa[4], unit = 0;
+      float sc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lab = (r[j] >> 13) & 0x7ffu;
+        opa[j] = ((r[j] & 0x1fffu) << 4) + rec_base;  // the operand state's record
+        sc[j] = *(const __attribute__((address_space(3))) float *)(uintptr_t)(tl_base + lab * 4);  // (null and unit label: -inf)
+        if (XM != 0 && g.a[j] >= 0) sc[j] += XM == 2 ? g.w[j] + g.s[XM == 2 ? j : 0] : g.w[j];
+        unit |= (((g.a[j] < 0) & ((int)lab == vocab + 1)) ? 1u : 0u) << j;
+      }
+      const bool any_unit = __builtin_amdgcn_ballot_w64(unit != 0) != 0;
+      while (__builtin_expect(prog_seen < t - R + 1, 0)) {  // the slot's previous tile is consumed
+        prog_seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)prog_a);
+        if (prog_seen < t - R + 1) __builtin_amdgcn_s_sleep(NFST_X_NAP);
+      }
+      asm volatile("" ::: "memory");
+      const uint32_t sb = ring_base + (uint32_t)(t % R) * SB;
+      const uint32_t dst = ((int)ctl < 0) ? ((ctl & 0xffffu) << 1) + rec_base : trash;  // 8 x state -> 16 x state
+      // word 0: store address (18 bits) | group size g (3) | largest g of the tile (3) | unit slots (4) | the tile has unit records (1);
+      // words 1 .. 3: all-ones where the state owns more than 2^s lanes (stage s of the segmented maximum)
+      const uint32_t gl = (ctl >> 20) & 7u;
+      const uint32_t w0 = dst | (gl << 18) | (((ctl >> 23) & 7u) << 21) | (unit << 24) | ((any_unit ? 1u : 0u) << 28);
+      *(lds_v4u *)(uintptr_t)(sb + lane * 16) = v4u{w0, gl > 0 ? ~0u : 0u, gl > 1 ? ~0u : 0u, gl > 2 ? ~0u : 0u};
+      *(lds_v4u *)(uintptr_t)(sb + 1024 + lane * 16) = v4u{opa[0], opa[1], opa[2], opa[3]};
+      *(lds_v4f *)(uintptr_t)(sb + 2048 + lane * 16) = v4f{sc[0], sc[1], sc[2], sc[3]};
+      // (the complement of the canonical arc: the low half of a 64-bit key whose maximum prefers the smaller arc)
+      *(lds_v4u *)(uintptr_t)(sb + 3072 + lane * 16) = v4u{~(uint32_t)g.a[0], ~(uint32_t)g.a[1], ~(uint32_t)g.a[2], ~(uint32_t)g.a[3]};
+      asm volatile("" ::: "memory");
+      *(volatile lds_u32 *)(uintptr_t)xl_a = (uint32_t)(t + 1);
+    };
+#define NFST_V_STEP(PU, GN, PL, GC)  \
+    GN = issue(PU);                  \
+    PL = ld_tile(i + 4, lane);       \
+    process(i, GC);
+    for (int i = 0; i < n_mine; i += 3) {
+      NFST_V_STEP(p2, g2, p1, g0) ++i;
+      NFST_V_STEP(p0, g0, p2, g1) ++i;
+      NFST_V_STEP(p1, g1, p0, g2) i -= 2;
+    }
+#undef NFST_V_STEP
+    *(volatile lds_u32 *)(uintptr_t)xl_a = 0x7fffffffu;
+  }
+};
+
+struct VitDec {
+  uint32_t w0, m0, m1, m2;
+  uint32_t opa[4];
+  float sc[4];
+  uint32_t narc[4];  // ~arc
+};
+__device__ __forceinline__ void vit_fetch(uint32_t sb, int lane, VitDec &d) {
+  const v4u h = *(const lds_v4u *)(uintptr_t)(sb + lane * 16);
+  const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 1024 + lane * 16);
+  const v4f s = *(const lds_v4f *)(uintptr_t)(sb + 2048 + lane * 16);
+  const v4u c = *(const lds_v4u *)(uintptr_t)(sb + 3072 + lane * 16);
+  d.w0 = h.x; d.m0 = h.y; d.m1 = h.z; d.m2 = h.w;
+  d.opa[0] = a.x; d.opa[1] = a.y; d.opa[2] = a.z; d.opa[3] = a.w;
+  d.sc[0] = s.x; d.sc[1] = s.y; d.sc[2] = s.z; d.sc[3] = s.w;
+  d.narc[0] = c.x; d.narc[1] = c.y; d.narc[2] = c.z; d.narc[3] = c.w;
+}
+
+template <int XM>
+__global__ __launch_bounds__(kVitTwThreads) void k_viterbi_tw(nfst_batch lat, nfst_scores sc, int R, float *best, int32_t *paths,
+                                                              int32_t *path_arcs, int32_t *lengths, int max_len, int pad) {
+  extern __shared__ float2 lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Meta m = load_meta(lat.meta, b);
+  const int tlw = (lat.vocab + 2 + 3) & ~3;
+  v4u *rec = (v4u *)lds;                       // per state: value bits, best arc, record address of its other end, -
+  float *tl = (float *)(rec + lat.max_rows);   // label scores
+  uint32_t *ring = (uint32_t *)(tl + tlw);
+  int *flags = (int *)(ring + (size_t)R * kSlotWords2);
+  const uint32_t rec_base = lds_addr(rec), trash = lds_addr(flags + kSweepFlags) + lane * 16;
+  const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
+  const bool x_wave = wv == 1 || wv == 2 || wv == 3 || wv == 5;
+  VitWave<XM> xw;
+  if (x_wave) xw.start(lat.bwd_stream + m.bwd_off, lat.bwd_perm + m.bwd_slot_off, m.bwd_tiles, ex, wv < 4 ? wv - 1 : 3, lane);
+  const float *tg = sc.theta + (size_t)sc.theta_stride * b;
+  for (int i = tid; i < lat.max_rows; i += kVitTwThreads) rec[i] = v4u{__float_as_uint(kNegInf), 0xffffffffu, 0u, 0u};  // incl. scratch rows
+  for (int i = tid; i < lat.vocab; i += kVitTwThreads) tl[i] = tg[i];
+  if (tid == 0) {
+    tl[lat.vocab] = kNegInf;    // the null label of empty slots
+    tl[lat.vocab + 1] = kNegInf;  // the unit label of carry / combine records: they compete through their operand's record
+    for (int i = 0; i < kSweepFlags; ++i) flags[i] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) rec[m.sink].x = __float_as_uint(0.0f);
+  __syncthreads();
+  if (x_wave) {
+    xw.run(ring, R, flags, flags + 4, tl, rec_base, trash, lat.vocab, lane);
+  } else if (wv == 0 && m.bwd_tiles > 0) {
+    __builtin_amdgcn_s_setprio(3);
+    constexpr uint32_t SB = kSlotWords2 * 4;
+    const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+    const uint32_t land_a = lds_addr(flags + 4), prog_a = lds_addr(flags);
+    auto group_margin = [&]() {
+      const v4u f = *(const volatile lds_v4u *)(uintptr_t)land_a;
+      return min(min((int)f.y - 1, (int)f.z - 2), min((int)f.w - 3, (int)f.x - 4));
+    };
+    while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32 *)(uintptr_t)land_a) <= 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    uint32_t gbase = ring_base;
+    int margin = 0;
+    VitDec da, db;
+    vit_fetch(gbase, lane, da);
+    asm volatile("" ::: "memory");
+    // tile T+K: `cur` in registers; fetches tile T+K+1 into `nxt`
+    auto step = [&](auto wide_tag, int T, int K, const VitDec &cur, VitDec &nxt) {
+      constexpr bool WIDE = decltype(wide_tag)::value;
+      const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.w0);  // the tile-uniform bits, read before they are needed
+      float xs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xs[j] = *(const __attribute__((address_space(3))) float *)(uintptr_t)cur.opa[j];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (K == 3) gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;
+      vit_fetch(gbase + (K == 3 ? 0u : (uint32_t)(K + 1) * SB), lane, nxt);
+      if (K == 3) margin = group_margin();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // (value, arc) as one 64-bit key -- order-preserving bits of the float above the complement of the arc -- so
+      // that "greater value, or equal value and smaller arc" is ONE vector compare feeding selects (the boolean
+      // form goes through scalar mask arithmetic: ~25 cycles per use of a fresh vector result)
+      auto ord = [](float x) { const uint32_t u = __float_as_uint(x); return u ^ (uint32_t)(((int)u >> 31) | (int)0x80000000); };
+      auto key = [](uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; };
+      uint32_t bh = ord(xs[0] + cur.sc[0]), bl = cur.narc[0], bn = cur.opa[0];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        const uint32_t oh = ord(xs[j] + cur.sc[j]);
+        const bool t = key(oh, cur.narc[j]) > key(bh, bl);
+        bh = t ? oh : bh; bl = t ? cur.narc[j] : bl; bn = t ? cur.opa[j] : bn;
+      }
+      // a unit-label record stands for what its operand row holds -- the state's own earlier pieces (carry) or a
+      // scratch row of a partial group: that row's best arc competes as such.  Rare (tile-uniform flag).
+      if (__builtin_expect((cu >> 28) & 1u, 0)) {
+        const uint32_t unit = (cur.w0 >> 24) & 0xfu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((unit >> j) & 1u) {
+            const v4u o = *(const lds_v4u *)(uintptr_t)cur.opa[j];
+            const uint32_t oh = ord(__uint_as_float(o.x));
+            if ((int)o.y >= 0 && key(oh, ~o.y) > key(bh, bl)) { bh = oh; bl = ~o.y; bn = o.z; }
+          }
+        }
+      }
+      // segmented maximum over the state's lanes: a partner outside the state's group is masked to the smallest key
+#define NFST_VIT_STAGE2(MASK, FI)                                            \
+      {                                                                     \
+        const uint32_t oh = (uint32_t)FI((int)bh) & (MASK), ol = (uint32_t)FI((int)bl), on = (uint32_t)FI((int)bn); \
+        const bool t = key(oh, ol) > key(bh, bl);                           \
+        bh = t ? oh : bh; bl = t ? ol : bl; bn = t ? on : bn;               \
+      }
+      NFST_VIT_STAGE2(cur.m0, dpp_i<0xB1>)
+      NFST_VIT_STAGE2(cur.m1, dpp_i<0x4E>)
+      NFST_VIT_STAGE2(cur.m2, dpp_i<0x141>)
+      if (WIDE) {
+        const int gl = (int)((cur.w0 >> 18) & 7u), gmax = (int)((cu >> 21) & 7u);
+#define NFST_SHFL16(x) __shfl_xor(x, 16)
+#define NFST_SHFL32(x) __shfl_xor(x, 32)
+        if (gmax > 3) NFST_VIT_STAGE2(gl > 3 ? ~0u : 0u, dpp_i<0x140>)
+        if (gmax > 4) NFST_VIT_STAGE2(gl > 4 ? ~0u : 0u, NFST_SHFL16)
+        if (gmax > 5) NFST_VIT_STAGE2(gl > 5 ? ~0u : 0u, NFST_SHFL32)
+#undef NFST_SHFL16
+#undef NFST_SHFL32
+      }
+#undef NFST_VIT_STAGE2
+      const uint32_t vb = bh ^ (uint32_t)((~(int)bh >> 31) | (int)0x80000000);  // back to float bits
+      *(lds_v4u *)(uintptr_t)(cur.w0 & 0x3ffffu) = v4u{vb, ~bl, bn, 0u};
+      if (K & 1) *(volatile lds_u32 *)(uintptr_t)prog_a = (uint32_t)(T + K + 2);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait_group = [&](int T) {
+      while (__builtin_amdgcn_readfirstlane(group_margin()) <= T) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    };
+    auto sweep = [&](auto wide_tag) {
+      for (int T = 0; T < m.bwd_tiles; T += 4) {
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin) <= T, 0)) wait_group(T);
+        step(wide_tag, T, 0, da, db); if (T + 1 >= m.bwd_tiles) break;
+        step(wide_tag, T, 1, db, da); if (T + 2 >= m.bwd_tiles) break;
+        step(wide_tag, T, 2, da, db); if (T + 3 >= m.bwd_tiles) break;
+        step(wide_tag, T, 3, db, da);
+      }
+    };
+    if (m.bwd_wide) sweep(std::true_type{}); else sweep(std::false_type{});
+    __builtin_amdgcn_s_setprio(0);
+  }
+  __syncthreads();
+  // lane 0 walks the back pointers inside LDS (arc ids go to the list `pa` in the ring, which is free now);
+  // all threads then write the labels
+  int *pa = (int *)ring;
+  int *res = flags;  // [0] length, [1] reached the sink
+  if (tid == 0) {
+    best[b] = __uint_as_float(rec[0].x);
+    uint32_t at = rec_base;
+    const uint32_t sink_at = rec_base + (uint32_t)m.sink * 16;
+    int len = 0;
+    const int cap = min(min(max_len, m.n_rows), R * kSlotWords2);
+    while (at != sink_at && len < cap) {
+      const v4u o = *(const lds_v4u *)(uintptr_t)at;
+      if ((int)o.y < 0) break;
+      pa[len++] = (int)o.y;
+      at = o.z;
+    }
+    res[0] = len;
+    res[1] = (at == sink_at) ? 1 : 0;
+  }
+  __syncthreads();
+  const int len = res[0];
+  if (tid == 0) lengths[b] = res[1] ? len : -1;
+  for (int j = tid; j < max_len; j += kVitTwThreads) {
+    const int a = j < len ? pa[j] : -1;
+    paths[(size_t)b * max_len + j] = a >= 0 ? lat.arc_label[a] : pad;
+    if (path_arcs) path_arcs[(size_t)b * max_len + j] = a;
+  }
+}
+
 // ------------------------------------------------------------------ sampling
 __device__ __forceinline__ uint32_t mulhilo(uint32_t a, uint32_t b, uint32_t *hi) {
   const uint64_t p = (uint64_t)a * b;
