@@ -310,12 +310,18 @@ int nfst_sample_paths(const nfst_batch *lat, const nfst_scores *scores, const fl
     return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16) return NFST_ERR_ARG;
   const int stage_theta = (int64_t)lat->max_rows * 8 + (int64_t)lat->vocab * 4 <= 96 * 1024;
-  const int64_t lds = (int64_t)lat->max_rows * 8 + (stage_theta ? (int64_t)lat->vocab * 4 : 0);
+  const int64_t lds_min = (int64_t)lat->max_rows * 8 + (stage_theta ? (int64_t)((lat->vocab + 3) & ~3) * 4 : 0);
+  // room for a lattice's CSR (row pointers + 6 bytes per arc; a program's slots bound its arcs): the kernel stages it
+  // when it fits what it was given
+  const int64_t csr = ((int64_t)lat->max_rows + 8) * 4 + ((int64_t)lat->max_tiles * 256 + 8) * 6;
+  const int64_t lds = lds_min + csr <= kMaxLds ? lds_min + csr : (lds_min + 64 * 1024 <= kMaxLds ? kMaxLds : lds_min);
   if ((rc = set_lds(k_sample, lds))) return rc;
-  hipLaunchKernelGGL(k_sample, dim3(lat->n_lattices, (k + kWalksPerBlock - 1) / kWalksPerBlock), dim3(kSampleThreads),
+  // 16 walks per 256 threads; up to 64 walks (1024 threads) of a lattice in one block share its staged data
+  const int walks = k >= 64 ? 64 : ((k + 15) / 16) * 16;
+  hipLaunchKernelGGL(k_sample, dim3(lat->n_lattices, (k + walks - 1) / walks), dim3(walks * 16),
                      (size_t)lds, (hipStream_t)stream,
                      *lat, *scores, (const float2 *)beta_me, logz64, (int)k, (int)max_len, uniforms,
-                     seed, (int)pad, stage_theta, paths, path_arcs, lengths, logq, status);
+                     seed, (int)pad, stage_theta, (int)lds, paths, path_arcs, lengths, logq, status);
   return hip_status(hipGetLastError());
 }
 

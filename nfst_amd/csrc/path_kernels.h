@@ -537,28 +537,40 @@ __device__ __forceinline__ float arc_score(const float *theta, const float *arc_
 // lattice's beta values staged in LDS, the CDF is an inclusive scan inside the row
 // (row_shr 1, 2, 4, 8 with zero fill) and the first lane with u < cdf wins (arcs with p = 0
 // never do).  A block is 16 walks of one lattice.
-constexpr int kSampleThreads = 256, kWalksPerBlock = kSampleThreads / 16;
+
 template <int SHIFT>
 __device__ __forceinline__ float row_shr_zero(float v) {  // lane i gets lane i-SHIFT of its row, 0 if there is none
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SHIFT, 0xf, 0xf, true));
 }
-__global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_scores sc,
+__global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
                                                            const float2 *beta_me, const double *logz64, int K,
                                                            int max_len, const float *uniforms, uint64_t seed,
-                                                           int pad, int stage_theta, int32_t *paths, int32_t *path_arcs,
-                                                           int32_t *lengths, float *logq, int32_t *status) {
+                                                           int pad, int stage_theta, int lds_bytes, int32_t *paths,
+                                                           int32_t *path_arcs, int32_t *lengths, float *logq, int32_t *status) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int r = tid & 15;                                // lane within the row
-  const int k = blockIdx.y * kWalksPerBlock + (tid >> 4);  // this row's walk
+  const int nt = (int)blockDim.x;                        // 256 .. 1024 threads: 16 .. 64 walks of one lattice share the staged data
+  const int k = blockIdx.y * (nt >> 4) + (tid >> 4);     // this row's walk
   const Meta m = load_meta(lat.meta, b);
   const float *theta = sc.theta + (size_t)sc.theta_stride * b;
   const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
   const int32_t *rp = lat.row_ptr + m.row_off + b;
   float2 *bl = lds;                                      // beta (m, e) of the lattice's rows
   float *tls = (float *)(bl + lat.max_rows);             // label scores (staged unless the vocabulary is huge)
-  for (int i = tid; i < m.n_rows; i += kSampleThreads) bl[i] = beta_me[m.row_off + i];
-  if (stage_theta) for (int i = tid; i < lat.vocab; i += kSampleThreads) tls[i] = theta[i];
+  for (int i = tid; i < m.n_rows; i += nt) bl[i] = beta_me[m.row_off + i];
+  if (stage_theta) for (int i = tid; i < lat.vocab; i += nt) tls[i] = theta[i];
+  // Round 2: when the lattice's CSR (row pointers, src | dst << 16, 16-bit labels: 6 bytes per arc) fits the LDS the
+  // launch was given, it is staged there: a step's dependent reads (row pointers -> arcs -> beta of their ends) are then
+  // LDS round trips instead of L2 / HBM ones (BASELINE batch: k_sample 105 -> 88 us, rocprofv3)
+  int *rps = (int *)(tls + (stage_theta ? ((lat.vocab + 3) & ~3) : 0));
+  uint32_t *sds = (uint32_t *)(rps + ((m.n_rows + 1 + 3) & ~3));
+  uint16_t *lbs = (uint16_t *)(sds + ((m.n_arcs + 3) & ~3));
+  const bool staged = (char *)(lbs + m.n_arcs) - (char *)lds <= (ptrdiff_t)lds_bytes;
+  if (staged) {
+    for (int i = tid; i <= m.n_rows; i += nt) rps[i] = rp[i] - m.arc_off;
+    for (int i = tid; i < m.n_arcs; i += nt) { sds[i] = lat.arc_sd[m.arc_off + i]; lbs[i] = lat.arc_l16[m.arc_off + i]; }
+  }
   __syncthreads();
   const float *tl = stage_theta ? (const float *)tls : theta;
   const bool live = k < K;
@@ -585,8 +597,8 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
         u = (t & 3) == 0 ? ublk[0] : ((t & 3) == 1 ? ublk[1] : ((t & 3) == 2 ? ublk[2] : ublk[3]));
       }
       bs = bl[s];
-      a0 = rp[s];
-      a1 = rp[s + 1];
+      a0 = staged ? rps[s] + m.arc_off : rp[s];
+      a1 = staged ? rps[s + 1] + m.arc_off : rp[s + 1];
     }
     const float rs = 1.0f / bs.x;
     const int es = __float_as_int(bs.y);
@@ -598,10 +610,10 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
       float p = 0.0f, x = 0.0f;
       int d = 0;
       if (more && a < a1) {
-        const uint32_t sd = lat.arc_sd[a];
+        const uint32_t sd = staged ? sds[a - m.arc_off] : lat.arc_sd[a];
         d = (int)(sd >> 16);
         if (d != s) {
-          x = tl[lat.arc_l16[a]];
+          x = tl[staged ? lbs[a - m.arc_off] : lat.arc_l16[a]];
           if (arc_w) x += arc_w[a];
           if (sc.arc_scores) x += sc.arc_scores[a];
           const ME wgt = exp_split(x);
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(nfst_batch lat, nfst_
       if (chosen < 0) { ok = false; active = false; }
       else {
         if (r == 0) {
-          out[t] = lat.arc_l16[chosen];
+          out[t] = staged ? lbs[chosen - m.arc_off] : lat.arc_l16[chosen];
           if (outa) outa[t] = chosen;
         }
         tot += sc_ch;

@@ -70,4 +70,17 @@ for H in (256, 64, 8):
     states = int(lat.meta_host[:, 9].sum())
     out[f"backward_neural_H{H}"] = {"ms": t * 1e3, "arcs/s": arcs / t,
                                    "GFLOP/s": (2.0 * states * H * H + 4.0 * arcs * H) / t / 1e9}
+    # its gradient (nfst_backward_neural_grad + two library GEMMs), forward pass not included
+    pg = [x.clone().requires_grad_(True) for x in prm]
+    r = ops.backward_neural(lat, *pg)
+    fin = torch.isfinite(r.log_beta)
+    loss = r.log_beta[fin].sum()
+    t = timeit(lambda: torch.autograd.grad(loss, pg, retain_graph=True), n=5, w=1)
+    out[f"backward_neural_grad_H{H}"] = {"ms": t * 1e3, "arcs/s": arcs / t}
+    del pg, r, loss
+asc = torch.randn(lat.total_arcs, device=dev) * 0.1
+t = timeit(lambda: ops.viterbi(lat, theta, arc_scores=asc), n=10, w=2)
+out["viterbi_with_arc_scores"] = {"ms": t * 1e3, "arcs/s": arcs / t}
+t = timeit(lambda: ops.backward(lat, theta, arc_scores=asc, want_logbeta=True))
+out["backward_with_arc_scores"] = {"ms": t * 1e3, "arcs/s": arcs / t}
 print(json.dumps(out, indent=1))
