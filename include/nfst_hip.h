@@ -114,6 +114,10 @@ extern "C" {
 /* nfst_batch.reserved0 bit: every tile program of the batch is in the compact format (code 8): the
  * fused sweep kernels apply (set by the packer; LatticeBatch.concat keeps it if all parts have it) */
 #define NFST_BATCH_ALL_COMPACT 1
+/* nfst_batch.reserved0 bits 8 .. 30: the largest number of canonical arcs of one lattice of the batch (capped: the cap
+ * means "unknown, large"); the launchers size LDS-resident per-arc data with it */
+#define NFST_BATCH_MAX_ARCS_SHIFT 8
+#define NFST_BATCH_MAX_ARCS_CAP 0x7fffff
 
 typedef struct nfst_batch {
   int32_t n_lattices;
@@ -121,7 +125,7 @@ typedef struct nfst_batch {
   int32_t max_rows;        /* max over the batch of the LDS rows a lattice needs: n_rows + scratch rows of its tile programs */
   int32_t max_tiles;       /* max tiles of one program over the batch */
   int32_t weighted;        /* arc_w holds the table's float weights */
-  int32_t reserved0;       /* flags: NFST_BATCH_ALL_COMPACT */
+  int32_t reserved0;       /* NFST_BATCH_ALL_COMPACT | largest arc count of one lattice << NFST_BATCH_MAX_ARCS_SHIFT */
   int64_t total_rows;
   int64_t total_arcs;
   int64_t total_dp_arcs;

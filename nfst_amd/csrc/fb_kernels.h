@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   const bool tw_v2 = TW && m.bwd_wide == 0;
   if (x_wave) {
     run_weights<kNE, EXTRA, TW>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, x_index, ring, R, flags, th, beta,
-                                tw_v2, lds_addr(flags + kSweepFlags) + lane * 8, lane);
+                                tw_v2, lds_addr(flags + kSweepFlags) + lane * 8, 0u, 0, lane);
   } else if constexpr (TW) {
     if (wv == 0) {
       __builtin_amdgcn_s_setprio(3);
@@ -103,19 +103,23 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
 }
 
 // ------------------------------------------------------------------ forward-backward
+// exp of a per-arc extra as (mantissa, exponent) on the hardware exp2 after a Cody-Waite reduction (relative error
+// ~1e-7: a posterior needs no more; the sweeps' weights come from exp_split).  Below -9e7: weight zero.
+__device__ __forceinline__ void exp_me_fast(float extra, float &m, int &e) {
+  const float x = fminf(fmaxf(extra, -1.0e8f), 9.0e7f);
+  const float kf = rintf(x * 1.44269504088896341f);
+  float t = fmaf(-kf, 0.693145751953125f, x);
+  t = fmaf(-kf, 1.42860682030941723e-6f, t);
+  m = __builtin_amdgcn_exp2f(t * 1.44269504088896341f);
+  e = (int)kf;
+}
 __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv, const float2 tw, float rz,
-                                               int ez, bool has_extra, float extra) {
+                                               int ez, bool has_extra, float mx, int ex) {
   float mw = tw.x;
   int ew = __float_as_int(tw.y);
   if (has_extra) {
-    // exp of the per-arc extra on the hardware exp2 after a Cody-Waite reduction (relative error ~1e-7:
-    // a posterior needs no more; the sweeps' weights come from exp_split).  Below -9e7: weight zero.
-    const float x = fminf(fmaxf(extra, -1.0e8f), 9.0e7f);
-    const float kf = rintf(x * 1.44269504088896341f);
-    float t = fmaf(-kf, 0.693145751953125f, x);
-    t = fmaf(-kf, 1.42860682030941723e-6f, t);
-    mw *= __builtin_amdgcn_exp2f(t * 1.44269504088896341f);
-    ew += (int)kf;
+    mw *= mx;
+    ew += ex;
   }
   const float mm = (av.x * mw) * (bv.x * rz);
   const int ee = __float_as_int(av.y) + ew + __float_as_int(bv.y) - ez;
@@ -151,6 +155,12 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   uint32_t *ring = (uint32_t *)(gth + plan.v4);
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   constexpr bool has_extra = EXTRA != 0;
+  // EXTRA = 3 (tile waves only): the lattice's per-arc extras -- table weights + caller scores, summed -- are staged in LDS at
+  // kernel entry with coalesced reads (RS carries the room in floats); the tile waves and the posterior pass gather them there
+  // instead of from HBM / L2 (the alpha side's random 4-byte gathers kept the CU's vector memory pipeline busy for longer than
+  // a tile takes); needs room for eight ring slots per sweep beside the extras: lattices up to ~14k arcs
+  constexpr bool kCached = EXTRA == 3;
+  static_assert(!kCached || TW, "staged extras: tile-wave kernels");
   static_assert(!TW || (NT == 1024 && !FUSED), "tile waves: the one-lattice-per-CU flavour");
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // even waves work for the beta sweep, odd waves for alpha: waves 0 / 1 sweep, 2 / 3 decode,
@@ -206,6 +216,28 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   if (x_wave && my_u == 8) xw8.start_gathers(lane);
   __syncthreads();
   int *flags = (int *)(ring + 2 * (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA)));
+  float *xc = (float *)(flags + 2 * kSweepFlags + 256);  // (behind the flags and the 1 KiB of trash)
+  const int xc_first = m.arc_off & ~3;
+  if (kCached) {
+    // 16 bytes at a time over the aligned interior, scalar at the ends (nothing is read outside the lattice's arcs)
+    const int a_lo = m.arc_off, a_hi = m.arc_off + m.n_arcs;
+    for (int a = xc_first + 4 * tid; a < a_hi; a += 4 * NT) {
+      float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (a >= a_lo && a + 4 <= a_hi) {
+        if (ex.arc_w) x = *reinterpret_cast<const float4 *>(ex.arc_w + a);
+        if (ex.arc_scores) {
+          const float4 y = *reinterpret_cast<const float4 *>(ex.arc_scores + a);
+          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+      } else {
+        float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < 4; ++q)
+          if (a + q >= a_lo && a + q < a_hi) t[q] = ex.at(a + q);
+        x = make_float4(t[0], t[1], t[2], t[3]);
+      }
+      *reinterpret_cast<float4 *>(xc + (a - xc_first)) = x;
+    }
+  }
   if (tid == 0) {
     beta[m.sink] = make_float2(0.5f, __int_as_float(1));
     alpha[0] = make_float2(0.5f, __int_as_float(1));
@@ -226,10 +258,14 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // src | dst << 16 and the label of 4 consecutive canonical arcs: 16 + 8 bytes
   uint4 psd[kPre > 0 ? kPre : 1];
   uint2 plb[kPre > 0 ? kPre : 1];
-  float4 pxe[kPre > 0 ? kPre : 1];  // their per-arc extras (kernels with extras: 15.1 -> ... us of tail when fetched after the sweeps)
+  // exp of their per-arc extras as (mantissa, exponent), computed while the sweeps run: fetched and exponentiated after the
+  // sweeps they doubled the posterior pass (7.5 -> 15 us)
+  float4 pxm[kPre > 0 ? kPre : 1];
+  int4 pxe[kPre > 0 ? kPre : 1];
   // the per-arc extras of 4 consecutive canonical arcs (16-byte loads: a is a multiple of 4)
   auto extras4 = [&](int a) {
     float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (kCached) return *reinterpret_cast<const float4 *>(xc + (a - xc_first));
     if (has_extra) {
       if (ex.arc_w) x = *reinterpret_cast<const float4 *>(ex.arc_w + a);
       if (ex.arc_scores) {
@@ -246,7 +282,15 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       if (a < v_end) {
         psd[u] = *reinterpret_cast<const uint4 *>(lat.arc_sd + a);
         plb[u] = *reinterpret_cast<const uint2 *>(lat.arc_l16 + a);
-        if (has_extra) pxe[u] = extras4(a);
+        if (has_extra) pxm[u] = extras4(a);
+      }
+    }
+    if (has_extra) {
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const float4 x = pxm[u];
+        exp_me_fast(x.x, pxm[u].x, pxe[u].x); exp_me_fast(x.y, pxm[u].y, pxe[u].y);
+        exp_me_fast(x.z, pxm[u].z, pxe[u].z); exp_me_fast(x.w, pxm[u].w, pxe[u].w);
       }
     }
   };
@@ -262,7 +306,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     }
   } else if (x_wave) {
     run_weights<kNE, EXTRA, TW>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th,
-                                bwd_side ? beta : alpha, tw_v2, lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 512) + lane * 8, lane);
+                                bwd_side ? beta : alpha, tw_v2, lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 512) + lane * 8,
+                                lds_addr(xc), xc_first, lane);
   } else if constexpr (TW) {
     if (wv < 2) {
       int *fl = bwd_side ? flags : flags + kSweepFlags;
@@ -290,15 +335,16 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   }
   const float rz = (zme.x > 0.0f) ? 1.0f / zme.x : 0.0f;
   const int ez = __float_as_int(zme.y);
-  auto do_group = [&](const uint4 sd, const uint2 lb, int a, const float4 xe) {
-    const float xv[4] = {xe.x, xe.y, xe.z, xe.w};
+  auto do_group = [&](const uint4 sd, const uint2 lb, int a, const float4 xm, const int4 xe) {
+    const float xmv[4] = {xm.x, xm.y, xm.z, xm.w};
+    const int xev[4] = {xe.x, xe.y, xe.z, xe.w};
     const uint32_t sdv[4] = {sd.x, sd.y, sd.z, sd.w};
     const int ll[4] = {(int)(lb.x & 0xffffu), (int)(lb.x >> 16), (int)(lb.y & 0xffffu), (int)(lb.y >> 16)};
     float pp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int s0 = (int)(sdv[q] & 0xffffu), d0 = (int)(sdv[q] >> 16);
-      pp[q] = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[ll[q]], rz, ez, has_extra, xv[q]) : 0.0f;
+      pp[q] = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[ll[q]], rz, ez, has_extra, xmv[q], xev[q]) : 0.0f;
       if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
     }
     if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -307,7 +353,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
       const int a = v_begin + 4 * (u * kHelpers + (tid - kSweepThreads));
-      if (a < v_end) do_group(psd[u], plb[u], a, has_extra ? pxe[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+      if (a < v_end) do_group(psd[u], plb[u], a, pxm[u], pxe[u]);
     }
   }
   // the row outputs: every thread (the sweep waves start here, the others come when their preloaded
@@ -336,7 +382,13 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       for (int u = 0; u < kPB; ++u) {
         const int a = a0 + u * NT * 4;
         if (a >= v_end) break;
-        do_group(sd[u], lb[u], a, xe[u]);
+        float4 gm = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        int4 ge = make_int4(0, 0, 0, 0);
+        if (has_extra) {
+          exp_me_fast(xe[u].x, gm.x, ge.x); exp_me_fast(xe[u].y, gm.y, ge.y);
+          exp_me_fast(xe[u].z, gm.z, ge.z); exp_me_fast(xe[u].w, gm.w, ge.w);
+        }
+        do_group(sd[u], lb[u], a, gm, ge);
       }
     }
     // unaligned head and tail (at most 3 arcs each)
@@ -345,7 +397,10 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     if (tid < n_head + n_tail) {
       const int a = tid < n_head ? a_begin + tid : v_end + (tid - n_head);
       const int s0 = lat.arc_src[a], d0 = lat.arc_dst[a], l0 = lat.arc_label[a];
-      const float p = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[l0], rz, ez, has_extra, has_extra ? ex.at(a) : 0.0f) : 0.0f;
+      float hm = 1.0f;
+      int he = 0;
+      if (has_extra) exp_me_fast(kCached ? xc[a - xc_first] : ex.at(a), hm, he);
+      const float p = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[l0], rz, ez, has_extra, hm, he) : 0.0f;
       if (posterior) posterior[a] = p;
       if (grad_theta && p > 0.0f) atomicAdd(&gth[l0], p);
     }

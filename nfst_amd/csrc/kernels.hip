@@ -207,7 +207,7 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
                      !(no_fused && no_fused[0] == '1');
   // one lattice per CU: tile waves instead of loader + decoder (NFST_TW=0: the three-wave pipeline, for A/B runs)
   const char *tw_env = getenv("NFST_TW");
-  bool tw = false;
+  bool tw = false, cached = false;
   if (fused) cfg = {0, 0, lat->n_lattices > cus};
   else if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
   else if (!cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && !(tw_env && tw_env[0] == '0')) {
@@ -216,11 +216,23 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     const int64_t r = (kMaxLds - lds_reserve() - plan.fb_bytes(0, 0, extra)) / slot;
     cfg = {(int)(r > kMaxRing ? kMaxRing : r) & ~3, 0, false};  // (tile_sweep2 takes four tiles per trip: a multiple of four slots)
     if (cfg.R < 4) return NFST_ERR_LIMIT;
+    // per-arc extras staged in LDS (the sum of both arrays, 4 bytes per arc of the largest lattice) when a ring of at least
+    // eight slots per sweep still fits beside them (lattices up to ~14k arcs at 2k states); RS carries the room in floats
+    const int64_t max_arcs = ((int64_t)lat->reserved0 >> NFST_BATCH_MAX_ARCS_SHIFT) & NFST_BATCH_MAX_ARCS_CAP;
+    const char *xc_env = getenv("NFST_XCACHE");  // (NFST_XCACHE=0: gather from HBM / L2 instead, for A/B runs)
+    if (extra && max_arcs > 0 && max_arcs < NFST_BATCH_MAX_ARCS_CAP && !(xc_env && xc_env[0] == '0')) {
+      const int64_t words = (max_arcs + 8 + 3) & ~(int64_t)3;
+      const int64_t rc2 = ((kMaxLds - lds_reserve() - plan.fb_bytes(0, 0, extra) - words * 4) / slot) & ~(int64_t)3;
+      if (rc2 >= 8) {  // (with four slots per sweep the tile waves cannot run ahead: 69 us against 50 from HBM / L2 at 256 x 20k arcs)
+        cached = true;
+        cfg = {(int)(rc2 > kMaxRing ? kMaxRing : rc2), (int)words, false};
+      }
+    }
   }
   if (extra && (((uintptr_t)lat->fwd_perm | (uintptr_t)lat->bwd_perm | (uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 15))
     return NFST_ERR_ARG;  // (maps and extras are read 16 bytes at a time)
   const int R = cfg.R, RS = cfg.RS;
-  const int64_t lds = tw ? plan.fb_bytes(0, 0, extra) + (int64_t)R * kSlotWords2 * 4 * 2 : plan.fb_bytes(R, RS, extra);
+  const int64_t lds = tw ? plan.fb_bytes(0, 0, extra) + (int64_t)R * kSlotWords2 * 4 * 2 + (cached ? (int64_t)RS * 4 : 0) : plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
   {                                                                                                     \
     if ((rc = set_lds(k_forward_backward<NT, EX>, lds))) return rc;                                     \
@@ -252,7 +264,7 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     if (lat->n_lattices <= 2 * cus) NFST_LAUNCH_FUSED(512)
     else NFST_LAUNCH_FUSED(256)
   } else if (!cfg.self && tw) {
-    if (both) NFST_LAUNCH_TW(2) else if (extra) NFST_LAUNCH_TW(1) else NFST_LAUNCH_TW(0)
+    if (cached) NFST_LAUNCH_TW(3) else if (both) NFST_LAUNCH_TW(2) else if (extra) NFST_LAUNCH_TW(1) else NFST_LAUNCH_TW(0)
   } else if (!cfg.self) {
     if (both) NFST_LAUNCH_FB(1024, 2) else if (extra) NFST_LAUNCH_FB(1024, 1) else NFST_LAUNCH_FB(1024, 0)
   }
@@ -279,7 +291,7 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
   const int64_t tw_fixed = VitLds(lat->max_rows, lat->vocab).fixed();
   int64_t tw_r = (kMaxLds - tw_fixed) / ((int64_t)kSlotWords2 * 4);
   tw_r = (tw_r > kMaxRing ? kMaxRing : tw_r) & ~(int64_t)3;
-  if ((lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tw_r >= 4 && !(tw_env && tw_env[0] == '0') &&
+  if ((lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tw_r >= 8 && !(tw_env && tw_env[0] == '0') &&  // (its trips check four tiles ahead: eight slots)
       (!extra || (((uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 3) == 0) && ((uintptr_t)lat->bwd_perm & 15) == 0) {
     const int64_t lds = tw_fixed + tw_r * kSlotWords2 * 4;
 #define NFST_LAUNCH_VIT(XM)                                                                                          \

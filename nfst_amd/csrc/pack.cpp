@@ -392,7 +392,11 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
   v.n_lattices = B; v.vocab = vocab; v.max_rows = max_rows; v.max_tiles = max_tiles;
   bool all_compact = true;
   for (const Lat &L : lats) all_compact = all_compact && L.fwd_compact && L.bwd_compact;
-  v.weighted = weighted ? 1 : 0; v.reserved0 = all_compact ? NFST_BATCH_ALL_COMPACT : 0; v.total_rows = rows; v.total_arcs = arcs; v.total_dp_arcs = dp;
+  int64_t max_arcs = 0;
+  for (const Lat &L : lats) max_arcs = std::max<int64_t>(max_arcs, (int64_t)L.label.size());
+  v.weighted = weighted ? 1 : 0;
+  v.reserved0 = (all_compact ? NFST_BATCH_ALL_COMPACT : 0) | (int32_t)(std::min<int64_t>(max_arcs, NFST_BATCH_MAX_ARCS_CAP) << NFST_BATCH_MAX_ARCS_SHIFT);
+  v.total_rows = rows; v.total_arcs = arcs; v.total_dp_arcs = dp;
   v.fwd_words = fw + slack; v.bwd_words = bw + slack; v.fwd_slots = fs; v.bwd_slots = bs;
   v.meta = p->meta.data(); v.row_ptr = p->row_ptr.data(); v.arc_src = p->arc_src.data();
   v.arc_dst = p->arc_dst.data(); v.arc_label = p->arc_label.data();

@@ -702,8 +702,9 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 #ifndef NFST_X_NAP
 #define NFST_X_NAP 12
 #endif
-template <int F, int NE, int XM, bool FULL>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2)
+template <int F, int NE, int XM, bool FULL>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2; 3: their sum is staged in LDS)
 struct WeightWave {
+  static constexpr bool GATHER = XM == 1 || XM == 2, CACHED = XM == 3;
   // FULL: the wave decodes its tiles completely -- control words and operand addresses as well -- straight
   // from HBM into the decoded ring: no loader, no staging ring, no decoder wave (tile waves of the
   // one-lattice-per-CU kernels); otherwise a decoder wave writes those and waits for this wave's flag.
@@ -711,7 +712,7 @@ struct WeightWave {
   static constexpr bool BOTH = XM == 2;
   static constexpr int RW = F == 8 ? 4 : (FULL ? 1 : 0) + U;  // raw words of a tile per lane
   struct P { int a[XM != 0 ? U : 1]; uint32_t raw[RW]; };
-  struct G { float w[XM != 0 ? U : 1], s[BOTH ? U : 1]; uint32_t valid; uint32_t raw[RW]; };
+  struct G { float w[GATHER ? U : 1], s[BOTH ? U : 1]; int a[CACHED ? U : 1]; uint32_t valid; uint32_t raw[RW]; };
   P p0, p1, p2;
   G g0, g1, g2;
   const float *bw, *bs;
@@ -775,8 +776,9 @@ struct WeightWave {
 #pragma unroll
     for (int j = 0; j < (XM != 0 ? U : 0); ++j) {
       const int a = max(p.a[j], 0);
-      g.w[j] = bw[a];
+      if (GATHER) g.w[j] = bw[a];
       if (BOTH) g.s[j] = bs[a];
+      if (CACHED) g.a[j] = a;
       g.valid |= (p.a[j] >= 0 ? 1u : 0u) << j;
     }
 #pragma unroll
@@ -803,8 +805,9 @@ struct WeightWave {
   // v2 (FULL, four slots per lane, narrow groups): the decoded tile of tile_sweep2 -- per lane the store address
   // (the state's value for a leader lane, 8 bytes of trash otherwise) and the three 0 / 1 stage multipliers of the
   // segmented sum instead of the control word.  Tile waves use ring slots of kSlotWords2 words for every format.
+  // xc_base / xc_first (XM = 3): LDS address of the staged sums of the per-arc extras, and the canonical arc the first one belongs to
   __device__ __forceinline__ void run(uint32_t *ring, int R, const int *prog, int *xland, const float2 *th_, const float2 *val, bool v2,
-                                      uint32_t trash, int lane) {
+                                      uint32_t trash, uint32_t xc_base, int xc_first, int lane) {
     const uint32_t xl_a = lds_addr(xland) + (uint32_t)ei * 4;
     if (n_mine <= 0) {
       if (FULL) *(volatile lds_u32 *)(uintptr_t)xl_a = 0x7fffffffu;  // "every tile of mine is there" (there is none)
@@ -814,7 +817,7 @@ struct WeightWave {
     const uint32_t ring_base = lds_addr(ring), prog_a = lds_addr(prog);
     const uint32_t th_base = lds_addr(th_), val_base = lds_addr(val);
     int prog_seen = 0;
-    auto process = [&](int i, const G &g) {
+    auto process = [&](int i, const auto &g) {  // g: G, or P in kernels without extras
       const int t = ei + min(i, n_mine - 1) * NE;
       uint32_t ctl, opoff[U], lab8[U];
       unpack(g.raw, ctl, opoff, lab8);
@@ -825,14 +828,17 @@ struct WeightWave {
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         if (XM == 0) { o[j] = tw[j]; continue; }
-        const float xs = BOTH ? g.w[XM != 0 ? j : 0] + g.s[BOTH ? j : 0] : g.w[XM != 0 ? j : 0];
-        const ME x = exp_split_nb(((g.valid >> j) & 1u) ? xs : 0.0f);
-        o[j] = v2f{tw[j].x * x.m, __int_as_float(__float_as_int(tw[j].y) + x.e)};
+        if constexpr (XM != 0) {
+          const float xs = CACHED ? *(const __attribute__((address_space(3))) float *)(uintptr_t)(xc_base + (uint32_t)(g.a[CACHED ? j : 0] - xc_first) * 4)
+                                  : (BOTH ? g.w[GATHER ? j : 0] + g.s[BOTH ? j : 0] : g.w[GATHER ? j : 0]);
+          const ME x = exp_split_nb(((g.valid >> j) & 1u) ? xs : 0.0f);
+          o[j] = v2f{tw[j].x * x.m, __int_as_float(__float_as_int(tw[j].y) + x.e)};
+        }
       }
       while (__builtin_expect(prog_seen < t - R + 1, 0)) {  // the slot's previous tile is consumed
         prog_seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)prog_a);
         // (a blocked wave has its tile ready and the sweep is R - NE tiles behind: long naps, few issue slots)
-        if (prog_seen < t - R + 1) __builtin_amdgcn_s_sleep(NFST_X_NAP);
+        if (prog_seen < t - R + 1) { if (R >= 8) __builtin_amdgcn_s_sleep(NFST_X_NAP); else __builtin_amdgcn_s_sleep(1); }
       }
       asm volatile("" ::: "memory");
       const uint32_t sb = ring_base + (uint32_t)(t % R) * SB;
@@ -1211,19 +1217,25 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
   constexpr uint32_t SB = kSlotWords2 * 4;
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
   const uint32_t land_a = lds_addr(land), prog_a = lds_addr(prog);
-  // min over the four tiles T+1 .. T+4 of (their wave's flag - their offset): all four are decoded iff it exceeds T
+  // the four flags in one read: .x = min over the tiles T+1 .. T+3 of (their wave's flag - their offset): all three are decoded
+  // iff it exceeds T; .y = the same for tile T+4, which the trip's last step fetches (with a ring of four slots that tile can only
+  // be written once the trip has consumed its first tile)
   auto group_margin = [&]() {
     const v4u f = *(const volatile lds_v4u *)(uintptr_t)land_a;
-    return min(min((int)f.y - 1, (int)f.z - 2), min((int)f.w - 3, (int)f.x - 4));
+    return v2u{(uint32_t)min(min((int)f.y - 1, (int)f.z - 2), (int)f.w - 3), (uint32_t)((int)f.x - 4)};
   };
-  auto wait_group = [&](int T) {
-    while (__builtin_amdgcn_readfirstlane(group_margin()) <= T) __builtin_amdgcn_s_sleep(1);
+  auto wait_group = [&](int T, int which) {
+    for (;;) {
+      const v2u g = group_margin();
+      if (__builtin_amdgcn_readfirstlane((int)(which ? g.y : g.x)) > T) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
     asm volatile("" ::: "memory");
   };
   while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32 *)(uintptr_t)land_a) <= 0) __builtin_amdgcn_s_sleep(1);  // tile 0
   asm volatile("" ::: "memory");
   uint32_t gbase = ring_base;  // slot of the trip's first tile
-  int margin = 0;              // group_margin() as of the previous trip's last tile (per-lane copy)
+  v2u margin = {0u, 0u};       // group_margin() as of an earlier tile (per-lane copy)
   int ref = 0;     // the exponent the terms of a tile are aligned to (wave-uniform, a few tiles old)
   int dmax0 = 0;
   Dec2<U> da, db;
@@ -1236,9 +1248,12 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
     _Pragma("unroll") for (int j = 0; j < U; ++j) vv[j] = *(const lds_v2f *)(uintptr_t)CUR.opa[j];         \
     asm volatile("" ::: "memory");                                                                        \
     __builtin_amdgcn_sched_barrier(0); /* nothing is scheduled in front of the operand gathers */         \
-    if (K == 3) gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;                        \
+    if (K == 3) {                                                                                         \
+      gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;                                  \
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.y) <= T, 0)) wait_group(T, 1);      \
+    }                                                                                                     \
     dec2_fetch<U>(gbase + (K == 3 ? 0u : (K + 1) * SB), lane, NXT);                                       \
-    if (K == 3) margin = group_margin();                                                                  \
+    if (K == 1 || K == 3) margin = group_margin();                                                        \
     asm volatile("" ::: "memory");                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     const int dm_ = tile_math3<U>(CUR, vv, ref);                                                          \
@@ -1248,7 +1263,7 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
     __builtin_amdgcn_sched_barrier(0);                                                                    \
   }
   for (int T = 0; T < n_tiles; T += 4) {
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin) <= T, 0)) wait_group(T);
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
     NFST_S2_STEP(0, da, db) if (T + 1 >= n_tiles) break;
     NFST_S2_STEP(1, db, da) if (T + 2 >= n_tiles) break;
     NFST_S2_STEP(2, da, db) if (T + 3 >= n_tiles) break;
@@ -1266,26 +1281,27 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
 template <int NE, int XM, bool FULL>
 __device__ __forceinline__ void run_weights(WeightWave<8, NE, XM, FULL> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
                                             int n_tiles, const Extra ex, int ei, uint32_t *ring, int R, int *flags,
-                                            const float2 *th, const float2 *val, bool v2, uint32_t trash, int lane) {
+                                            const float2 *th, const float2 *val, bool v2, uint32_t trash, uint32_t xc_base, int xc_first,
+                                            int lane) {
   const int *prog = flags;
   int *xland = flags + 4;
   if (F == 8 || FULL) {  // (tile waves run all-compact batches only)
-    x8.run(ring, R, prog, xland, th, val, v2, trash, lane);
+    x8.run(ring, R, prog, xland, th, val, v2, trash, xc_base, xc_first, lane);
   } else if (F == 4) {
     WeightWave<4, NE, XM, FULL> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
-    x.run(ring, R, prog, xland, th, val, v2, trash, lane);
+    x.run(ring, R, prog, xland, th, val, v2, trash, xc_base, xc_first, lane);
   } else if (F == 2) {
     WeightWave<2, NE, XM, FULL> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
-    x.run(ring, R, prog, xland, th, val, v2, trash, lane);
+    x.run(ring, R, prog, xland, th, val, v2, trash, xc_base, xc_first, lane);
   } else {
     WeightWave<1, NE, XM, FULL> x;
     x.start_maps(prog_words, perm, n_tiles, ex, ei, lane);
     x.start_gathers(lane);
-    x.run(ring, R, prog, xland, th, val, v2, trash, lane);
+    x.run(ring, R, prog, xland, th, val, v2, trash, xc_base, xc_first, lane);
   }
 }
 

@@ -196,7 +196,8 @@ class LatticeBatch:
                 x = torch.cat([x, torch.zeros(8, dtype=x.dtype)])
             tensors[k] = x.contiguous()
         header = dict(h0)
-        header.update(reserved0=min(b._h["reserved0"] & 1 for b in cpu),  # all-compact only if every part is
+        header.update(reserved0=min(b._h["reserved0"] & 1 for b in cpu)  # all-compact only if every part is
+                      | (max(b._h["reserved0"] >> 8 for b in cpu) << 8),  # (the largest arc count of one lattice)
                       n_lattices=sum(b._h["n_lattices"] for b in cpu), max_rows=max(b._h["max_rows"] for b in cpu),
                       max_tiles=max(b._h["max_tiles"] for b in cpu), total_rows=rows, total_arcs=arcs,
                       total_dp_arcs=sum(b._h["total_dp_arcs"] for b in cpu), fwd_words=fw + SLACK, bwd_words=bw + SLACK,
