@@ -331,6 +331,29 @@ def make_gather():
                 f"{tag}_mask_len21": masks_long,
             }
         )
+    # float emission tables (weighted machines, scorers.py:1011-1027): mask_out_invalid adds the state's row of log
+    # weights (1049-1053); and the beta-logit gather of the use_beta proposal (scorers.py:581-593) on the same tables
+    wl = [synth.layered_lattice(23 + i, n_states=16 + 9 * i, avg_degree=3.0, vocab=V, width=3, span=2, weighted=True) for i in range(3)]
+    em, tr = synth.collate_dense([l.dense(weighted=True) for l in wl], pad=0)
+    K = 3
+    sc = FSAMaskScorer(hid_dim=4, vocab_size=V, pad=PAD, bos=BOS, eos=EOS, max_length=20)
+    sc.set_masks(emission=torch.from_numpy(em), transition=torch.from_numpy(tr))
+    sc.set_k(K)
+    N, reps = len(wl) * K, 30
+    states = np.zeros((reps, N), dtype=np.int64)
+    labels = rng.integers(0, V, size=(reps, N)).astype(np.int64)
+    for n in range(N):
+        states[:, n] = rng.integers(0, wl[n // K].n_rows, size=reps)
+    beta = rng.normal(size=(N, em.shape[1])).astype(np.float32)
+    masks = np.zeros((reps, N, V), dtype=np.float32)
+    blog = np.zeros((reps, N, V), dtype=np.float32)
+    for r in range(reps):
+        st = torch.from_numpy(states[r])
+        masks[r] = sc.mask_out_invalid(torch.from_numpy(labels[r]), {"state": st, "length": 5}).numpy()
+        transition = sc.transition_k[torch.arange(st.shape[0]), st]          # scorers.py:584-588
+        blog[r] = torch.gather(torch.from_numpy(beta), 1, transition).numpy()  # :589
+    out.update(w_emission=em, w_transition=tr, w_states=states, w_labels=labels, w_mask_len5=masks, w_beta=beta, w_beta_logits=blog,
+               w_n_rows=np.array([l.n_rows for l in wl], dtype=np.int64))
     out["K"] = np.int64(3)
     out["max_length"] = np.int64(20)
     out["n_rows"] = np.array([l.n_rows for l in lats], dtype=np.int64)

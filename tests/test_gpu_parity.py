@@ -105,6 +105,34 @@ def test_state_advance_and_masks_bit_exact(dev, golden_dir, tag):
             assert np.array_equal(got, d[f"{tag}_{key}"][r])
 
 
+def test_weighted_masks_and_beta_logits_fixture(dev, golden_dir):
+    """nfst_emission_mask on float emission tables (the state's row of log weights on top of the legality masks,
+    scorers.py:1049-1053) and nfst_beta_logits (scorers.py:584-590) against arrays the reference produced."""
+    d = load(golden_dir, "gather")
+    K, maxlen = int(d["K"]), int(d["max_length"])
+    lat = LatticeBatch.from_dense(d["w_emission"], d["w_transition"], device=dev)
+    assert lat.weighted
+    # the reference's beta is [B*K, S+1] over the collated row count; the engine's values are per packed row
+    S1 = d["w_emission"].shape[1]
+    beta = d["w_beta"]
+    for r in range(d["w_states"].shape[0]):
+        st = torch.from_numpy(d["w_states"][r]).to(dev)
+        lb = torch.from_numpy(d["w_labels"][r]).to(dev)
+        got = ops.emission_mask(lat, st, k=K, inp=lb, pad=PAD, bos=BOS, eos=EOS, has_to_end=5 > maxlen).cpu().numpy()
+        assert np.array_equal(got, d["w_mask_len5"][r])
+    # beta logits: one values row per lattice (K = 1 walker per lattice takes the reference's rows 0, K, 2K, ...)
+    vals = np.zeros(lat.total_rows, np.float32)
+    for b in range(lat.n_lattices):
+        r0, n = int(lat.row_off[b]), int(lat.n_rows[b])
+        vals[r0:r0 + n] = beta[b * K, :n]
+    for r in range(d["w_states"].shape[0]):
+        st = torch.from_numpy(d["w_states"][r][::K].copy()).to(dev)
+        got = ops.beta_logits(lat, torch.from_numpy(vals).to(dev), st, k=1).cpu().numpy()
+        ref = d["w_beta_logits"][r][::K]
+        # labels without an arc lead to row 0 in the reference's dense table (transition 0): the engine returns the same row's value
+        assert np.array_equal(got, ref), r
+
+
 def test_iwae_and_wfst_fixture(dev, golden_dir):
     d = load(golden_dir, "iwae")
     B, K, T = d["samples"].shape

@@ -91,6 +91,21 @@ def test_state_advance_and_masks(golden_dir, tag):
             assert np.array_equal(got, d[f"{tag}_{key}"][r])
 
 
+def test_weighted_masks_and_beta_logits(golden_dir):
+    """Float emission tables (weighted machines: mask_out_invalid adds the state's row of log weights,
+    scorers.py:1049-1053) and the beta-logit gather of the use_beta proposal (scorers.py:584-590), both produced by
+    the reference on the same tables."""
+    d = load(golden_dir, "gather")
+    K = int(d["K"]); maxlen = int(d["max_length"])
+    tr_k = O.expand_k(d["w_transition"], K)
+    em_k = O.expand_k(d["w_emission"], K)
+    assert em_k.dtype == np.float32
+    for r in range(d["w_states"].shape[0]):
+        st, lb = d["w_states"][r], d["w_labels"][r]
+        assert np.array_equal(O.mask_out_invalid(em_k, lb, st, 5, maxlen, PAD, BOS, EOS), d["w_mask_len5"][r])
+        assert np.array_equal(O.beta_logits(tr_k, d["w_beta"], st), d["w_beta_logits"][r])
+
+
 def test_sampler_traces_are_accepting_paths(golden_dir):
     """Every reference sample is an accepting path and its log q is
     -sum log(out-degree) (uniform FSAMaskScorer proposal)."""
