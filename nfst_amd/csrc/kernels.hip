@@ -367,7 +367,8 @@ int nfst_emission_mask(const nfst_batch *lat, const int64_t *state, const int64_
   if (rc) return rc;
   if (!state || !out || k <= 0) return NFST_ERR_ARG;
   const int64_t n = (int64_t)lat->n_lattices * k;
-  hipLaunchKernelGGL(k_row_gather<0>, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, *lat, state,
+  if ((rc = set_lds(k_row_gather<0>, (int64_t)lat->vocab * 4))) return rc;
+  hipLaunchKernelGGL(k_row_gather<0>, dim3((unsigned)n), dim3(64), (size_t)lat->vocab * 4, (hipStream_t)stream, *lat, state,
                      (const float *)nullptr, inp, (int)pad, (int)bos, (int)eos, (int)has_to_end, out,
                      (int)k);
   return hip_status(hipGetLastError());
@@ -379,7 +380,8 @@ int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *
   if (rc) return rc;
   if (!values || !state || !out || k <= 0) return NFST_ERR_ARG;
   const int64_t n = (int64_t)lat->n_lattices * k;
-  hipLaunchKernelGGL(k_row_gather<1>, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, *lat, state,
+  if ((rc = set_lds(k_row_gather<1>, (int64_t)lat->vocab * 4))) return rc;
+  hipLaunchKernelGGL(k_row_gather<1>, dim3((unsigned)n), dim3(64), (size_t)lat->vocab * 4, (hipStream_t)stream, *lat, state,
                      values, (const int64_t *)nullptr, 0, 0, 0, 0, out, (int)k);
   return hip_status(hipGetLastError());
 }

@@ -719,14 +719,20 @@ __global__ void k_step(nfst_batch lat, const int64_t *state, const int64_t *labe
   next[i] = r;
 }
 
-// MODE 0: emission mask (0 / weight / -inf); MODE 1: values[row_off + transition[state, l]]
+// MODE 0: emission mask (0 / weight / -inf); MODE 1: values[row_off + transition[state, l]].
+// One wave per walker: the row of V outputs is built in LDS -- filled with the value of "no arc", then the state's arcs
+// (a coalesced read of their labels and weights / destinations) scatter theirs -- and written out with the legality masks
+// applied.  (Round 1 searched the state's arcs for every label: V x log2(degree) dependent loads per walker, 1.3 TB/s.)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_row_gather(nfst_batch lat, const int64_t *state,
                                                    const float *values, const int64_t *inp, int pad,
                                                    int bos, int eos, int has_to_end, float *out,
                                                    int K) {
+  extern __shared__ float2 lds[];
+  float *row = (float *)lds;
   const int64_t i = blockIdx.x;
   const int b = (int)(i / K);
+  const int lane = threadIdx.x;
   const Meta m = load_meta(lat.meta, b);
   const int64_t s = state[i];
   int r0 = 0, r1 = 0;
@@ -734,20 +740,22 @@ __global__ __launch_bounds__(64) void k_row_gather(nfst_batch lat, const int64_t
     const int32_t *rp = lat.row_ptr + m.row_off + b;
     r0 = rp[s]; r1 = rp[s + 1];
   }
+  const float none = MODE == 0 ? kNegInf : values[m.row_off];  // a mark without an arc: -inf / the dense table's transition 0
+  for (int l = lane; l < lat.vocab; l += 64) row[l] = none;
+  for (int a = r0 + lane; a < r1; a += 64)  // (LDS accesses of one wave execute in order: no barrier)
+    row[lat.arc_label[a]] = MODE == 0 ? (lat.weighted ? lat.arc_w[a] : 0.0f) : values[m.row_off + lat.arc_dst[a]];
   float *o = out + (size_t)i * lat.vocab;
-  for (int l = threadIdx.x; l < lat.vocab; l += 64) {
-    const int a = find_arc(lat.arc_label, r0, r1, l);
-    float v;
-    if (MODE == 0) {
-      v = (a < 0) ? kNegInf : (lat.weighted ? lat.arc_w[a] : 0.0f);
-      if (inp) {
-        const int64_t p = inp[i];
-        const bool ended = (p == eos) || (p == pad);
-        if (l == bos || (ended ? (l != pad) : (l == pad))) v = kNegInf;
-        if (has_to_end && !ended && l != eos) v = kNegInf;
-      }
-    } else {
-      v = values[m.row_off + (a < 0 ? 0 : lat.arc_dst[a])];
+  bool ended = false, check = false;
+  if (MODE == 0 && inp) {
+    const int64_t p = inp[i];
+    ended = (p == eos) || (p == pad);
+    check = true;
+  }
+  for (int l = lane; l < lat.vocab; l += 64) {
+    float v = row[l];
+    if (MODE == 0 && check) {
+      if (l == bos || (ended ? (l != pad) : (l == pad))) v = kNegInf;
+      if (has_to_end && !ended && l != eos) v = kNegInf;
     }
     o[l] = v;
   }
