@@ -329,7 +329,10 @@ int nfst_sample_paths(const nfst_batch *lat, const nfst_scores *scores, const fl
   const int64_t lds = lds_min + csr <= kMaxLds ? lds_min + csr : (lds_min + 64 * 1024 <= kMaxLds ? kMaxLds : lds_min);
   if ((rc = set_lds(k_sample, lds))) return rc;
   // 16 walks per 256 threads; up to 64 walks (1024 threads) of a lattice in one block share its staged data
-  const int walks = k >= 64 ? 64 : ((k + 15) / 16) * 16;
+  // (with the arcs' probabilities precomputed per block -- path_arcs given and the CSR fits -- every block has 1024
+  // threads for that pass, whatever k)
+  const bool precdf = path_arcs && lds > lds_min;  // (the kernel decides per lattice, from its own arc count)
+  const int walks = (k >= 64 || precdf) ? 64 : ((k + 15) / 16) * 16;
   hipLaunchKernelGGL(k_sample, dim3(lat->n_lattices, (k + walks - 1) / walks), dim3(walks * 16),
                      (size_t)lds, (hipStream_t)stream,
                      *lat, *scores, (const float2 *)beta_me, logz64, (int)k, (int)max_len, uniforms,
