@@ -448,11 +448,24 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
     hipLaunchKernelGGL(k_backward_neural<HC>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,          \
                        (hipStream_t)stream, *lat, label_x, wh, w, (int)hid, log_beta, beta_hat, ws);        \
   } while (0)
-  if (hid <= 64) NFST_LAUNCH_NEU(1);
+#define NFST_LAUNCH_NEU_SMALL(LPR)                                                                             \
+  do {                                                                                                        \
+    if ((rc = set_lds(k_backward_neural_small<LPR>, lds))) return rc;                                         \
+    hipLaunchKernelGGL(k_backward_neural_small<LPR>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,   \
+                       (hipStream_t)stream, *lat, label_x, wh, w, (int)hid, log_beta, beta_hat, ws);        \
+  } while (0)
+  static const int no_small = getenv("NFST_NEU_NO_SMALL") ? 1 : 0;  // (A/B against the two-phase kernel)
+  // BASELINE batch, whole op: H = 8 0.52 against 1.19 ms, 16 0.58 / 1.18, 32 1.07 / 1.19; with a whole wave per
+  // record (H = 64) the packed kernel has nothing to pack and loses to the two-phase one: 1.97 / 1.24
+  if (hid <= 8 && !no_small) NFST_LAUNCH_NEU_SMALL(8);
+  else if (hid <= 16 && !no_small) NFST_LAUNCH_NEU_SMALL(16);
+  else if (hid <= 32 && !no_small) NFST_LAUNCH_NEU_SMALL(32);
+  else if (hid <= 64) NFST_LAUNCH_NEU(1);
   else if (hid <= 128) NFST_LAUNCH_NEU(2);
   else if (hid <= 256) NFST_LAUNCH_NEU(4);
   else NFST_LAUNCH_NEU(8);
 #undef NFST_LAUNCH_NEU
+#undef NFST_LAUNCH_NEU_SMALL
   return hip_status(hipGetLastError());
 }
 

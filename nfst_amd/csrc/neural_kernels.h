@@ -353,6 +353,152 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small hidden sizes (hid <= LPR <= 32; round 2).  With lanes over the H components only, a wave of the kernel above
+// works on one record at a time and 64 - H of its lanes idle; a tile then costs its longest group's records / D
+// round trips to L2 plus the barriers of the second phase, whatever H is: 8.3 us per tile = 1.15 ms on the BASELINE
+// batch at H = 8.  Here a wave holds 64 / LPR records side by side, LPR lanes each (the records of a group D x 64 / LPR
+// at a time, their operand rows requested together), every record slot keeps its own running (mantissa, exponent,
+// vector) sum -- no cross-lane step inside the loop but the W . t sum within a record's LPR lanes, on DPP -- and the
+// slots are merged once per group.  u = Wh . beta_hat of the finished state is taken by the same wave straight away
+// (row h of Wh lives in lane h's registers, beta_hat[j] by v_readlane): no second phase, no LDS rows for it, one
+// barrier per tile.
+template <int LPR>
+__device__ __forceinline__ float neu_group_sum(float v) {  // sum over the LPR lanes of a record slot, in all of them
+  v += dpp_f<0xB1>(v);   // lane ^ 1
+  v += dpp_f<0x4E>(v);   // lane ^ 2
+  if (LPR >= 8) v += dpp_f<0x141>(v);   // half mirror
+  if (LPR >= 16) v += dpp_f<0x140>(v);  // row mirror
+  if (LPR >= 32) v += __shfl_xor(v, 16);
+  if (LPR >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kNeuThreads) void k_backward_neural_small(nfst_batch lat, const float *__restrict__ label_x,
+                                                                       const float *__restrict__ wh,
+                                                                       const float *__restrict__ wvec, int hid,
+                                                                       float *__restrict__ log_beta, float *beta_hat,
+                                                                       float *ws) {
+  extern __shared__ float2 lds[];
+  constexpr int RPB = 64 / LPR;                                   // record slots of a wave
+  constexpr int D = LPR <= 16 ? 4 : 6;                            // records per slot whose operands are in flight together
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane / LPR, h = lane % LPR;
+  const bool hv = h < hid;
+  const int hc = min(h, hid - 1);
+  const Meta m = load_meta(lat.meta, b);
+  float2 *bme = lds;
+  uint32_t *stage_s = (uint32_t *)(bme + lat.max_rows);
+  float *bh_w = ws + (size_t)b * lat.max_rows * hid;
+  float *u_w = ws + ((size_t)lat.n_lattices + b) * lat.max_rows * hid;
+  float *bh_out = beta_hat + (size_t)m.row_off * hid;
+  auto bh_row = [&](int r) { return r < m.n_rows ? bh_out + (size_t)r * hid : bh_w + (size_t)r * hid; };
+  const int F = m.bwd_u, U = fmt_u(F);
+  const uint32_t *prog = lat.bwd_stream + m.bwd_off;
+  const int32_t *perm = lat.bwd_perm + m.bwd_slot_off;
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  const int V = lat.vocab;
+
+  for (int i = tid; i < lat.max_rows; i += kNeuThreads) bme[i] = make_float2(0.0f, __int_as_float(kEZero));
+  for (int i = tid; i < hid; i += kNeuThreads) {
+    bh_out[(size_t)m.sink * hid + i] = 0.0f;
+    u_w[(size_t)m.sink * hid + i] = 0.0f;
+  }
+  const float wl = hv ? wvec[h] : 0.0f;
+  float whr[LPR];                                                 // row h of Wh ([out, in], row-major)
+#pragma unroll
+  for (int j = 0; j < LPR; ++j) whr[j] = (hv && j < hid) ? wh[(size_t)h * hid + j] : 0.0f;
+  __syncthreads();
+  if (tid == 0) bme[m.sink] = make_float2(0.5f, __int_as_float(1));  // beta(sink) = 1
+  if (wv == kNeuWaves - 1 && m.bwd_tiles > 0) neu_stage_tile(prog, perm, F, 0, stage_s, lane);
+  __threadfence_block();
+  __syncthreads();
+
+  for (int T = 0; T < m.bwd_tiles; ++T) {
+    uint32_t *st = stage_s + (T & 1) * kNeuStageWords;
+    const uint32_t *ctl_s = st, *rec_s = st + 64;
+    const int *cas_s = (const int *)(st + 320), *lead_s = (const int *)(st + 576), *nlead_s = (const int *)(st + 640);
+    if (wv == kNeuWaves - 1 && T + 1 < m.bwd_tiles)
+      neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuStageWords, lane);
+    const int n_lead = nlead_s[0];
+    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+      const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
+      const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
+      float macc = 0.0f, tacc = 0.0f;
+      int eacc = kEZero;
+      for (int q0 = 0; q0 < n_rec; q0 += D * RPB) {
+        float a[D], bb[D], x[D];
+        float2 bo[D];
+        bool real[D], act[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {  // (straight-line: a slot past the group's records reads row 0 and counts for nothing)
+          const int q = q0 + k * RPB + sub;
+          const bool in = q < n_rec;
+          const uint32_t rc = in ? rec_s[l0 * U + q] : 0u;
+          const int ca = in ? cas_s[l0 * U + q] : -1;
+          const int other = (int)((rc & 0xffffu) >> 3), lab = (int)(rc >> 16);
+          real[k] = ca >= 0;
+          act[k] = real[k] || lab == V + 1;
+          const float *pa = real[k] ? label_x + (size_t)lab * hid : bh_row(other);
+          a[k] = pa[hc];
+          bb[k] = u_w[(size_t)other * hid + hc];
+          x[k] = arc_w ? arc_w[max(ca, 0)] : 0.0f;
+          bo[k] = bme[other];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float t = neu_tanh(a[k] + bb[k]);
+          const float v = (hv && act[k]) ? (real[k] ? t : a[k]) : 0.0f;  // (what an idle slot read may be anything)
+          const float sc = neu_group_sum<LPR>(wl * v);
+          const ME w = exp_split_nb(sc + x[k]);
+          float wm = act[k] ? bo[k].x * (real[k] ? w.m : 1.0f) : 0.0f;
+          int we = max(__float_as_int(bo[k].y) + (real[k] ? w.e : 0), kEZero);
+          if (!(wm > 0.0f)) { wm = 0.0f; we = kEZero; }
+          const int en = max(eacc, we);
+          const float so = neu_scale(en - eacc), q = wm * neu_scale(en - we);
+          macc = fmaf(macc, so, q);
+          tacc = fmaf(tacc, so, q * v);
+          eacc = en;
+        }
+      }
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {  // merge the record slots
+        const int e2 = __shfl_xor(eacc, off);
+        const float m2 = __shfl_xor(macc, off), t2 = __shfl_xor(tacc, off);
+        const int en = max(eacc, e2);
+        const float s1 = neu_scale(en - eacc), s2 = neu_scale(en - e2);
+        macc = fmaf(macc, s1, m2 * s2);
+        tacc = fmaf(tacc, s1, t2 * s2);
+        eacc = en;
+      }
+      const float inv = macc > 0.0f ? 1.0f / macc : 0.0f;
+      const float bh = tacc * inv;
+      float u = 0.0f;
+#pragma unroll
+      for (int j = 0; j < LPR; ++j) u = fmaf(whr[j], read_lane_f(bh, j), u);
+      if (sub == 0 && hv) {
+        bh_row(sid)[h] = bh;
+        if (sid < m.n_rows) u_w[(size_t)sid * hid + h] = u;
+      }
+      if (lane == 0) bme[sid] = me_pack(macc, eacc);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+
+  float2 *bme_w = reinterpret_cast<float2 *>(ws + 2 * (size_t)lat.n_lattices * lat.max_rows * hid) + (size_t)b * lat.max_rows;
+  for (int r = tid; r < m.n_rows; r += kNeuThreads) {
+    log_beta[m.row_off + r] = me_log32(bme[r]);
+    bme_w[r] = bme[r];  // (mantissa, exponent) pairs for nfst_backward_neural_grad
+  }
+  for (int r = wv; r < m.n_rows; r += kNeuWaves)
+    if (!(bme[r].x > 0.0f))
+      for (int hh = lane; hh < hid; hh += 64) bh_out[(size_t)r * hid + hh] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gradient of the neuralised beta sweep (tune_proposal differentiates log q through compute_beta,
 // /root/reference/src/modules/lightning.py:339-406; parameters scorers.py:954-970).
 // With z_a = W . t_a (+ arc_w) + log beta(d), p_a = exp(z_a - log beta(s)) and
