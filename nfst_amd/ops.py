@@ -180,9 +180,11 @@ class SampleResult(NamedTuple):
 
 def sample_paths(lat: LatticeBatch, theta, k: int, arc_scores=None, max_len: Optional[int] = None,
                  uniforms: Optional[torch.Tensor] = None, seed: int = 0, pad: int = 0,
-                 beta: Optional[BackwardResult] = None) -> SampleResult:
+                 beta: Optional[BackwardResult] = None, want_arcs: bool = True) -> SampleResult:
     """K exact posterior samples per lattice (Sampler.sample, modules/samplers.py:137-335,
-    with the exact posterior as proposal)."""
+    with the exact posterior as proposal).  ``want_arcs=False`` leaves ``arcs`` None (the C entry
+    point's path_arcs is optional; with it the kernel precomputes every arc's probability once per
+    block, without it a walk computes the probabilities of the arcs it meets)."""
     _need_gpu(lat)
     sc, keep = _scores(lat, theta, arc_scores)
     if max_len is None:
@@ -196,7 +198,7 @@ def sample_paths(lat: LatticeBatch, theta, k: int, arc_scores=None, max_len: Opt
         if uniforms.shape != (B, k, max_len):
             raise ValueError(f"uniforms must be [{B}, {k}, {max_len}]")
     paths = torch.empty((B, k, max_len), dtype=torch.int32, device=dev)
-    arcs = torch.empty((B, k, max_len), dtype=torch.int32, device=dev)
+    arcs = torch.empty((B, k, max_len), dtype=torch.int32, device=dev) if want_arcs else None
     lens = torch.empty((B, k), dtype=torch.int32, device=dev)
     logq = torch.empty((B, k), dtype=torch.float32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -354,6 +354,40 @@ def test_posterior_sampling(dev):
         assert np.max(np.abs(cnt - o["posterior"])) < 0.06
 
 
+def test_posterior_sampling_kernel_modes(dev):
+    """The three ways k_sample reads a lattice -- cumulative arc probabilities precomputed in LDS (path_arcs wanted,
+    CSR fits), CSR staged in LDS (no path_arcs), global memory (a lattice too large for LDS) -- draw the same paths
+    from the same uniforms wherever u stays clear of a CDF boundary."""
+    theta = synth.label_scores(9, 64)
+    lats = _mixed_batch()[:4]
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    K, T = 96, int(lat.depth.max()) + 1
+    u = torch.from_numpy(np.random.default_rng(3).random((len(lats), K, T)).astype(np.float32))
+    a = ops.sample_paths(lat, torch.from_numpy(theta), K, max_len=T, uniforms=u, pad=PAD)
+    b = ops.sample_paths(lat, torch.from_numpy(theta), K, max_len=T, uniforms=u, pad=PAD, want_arcs=False)
+    assert b.arcs is None
+    same = (a.paths == b.paths).all(dim=2)
+    assert same.float().mean() > 0.995  # (running sums against a DPP scan: the last bit of a CDF value may differ)
+    assert torch.equal(a.lengths[same], b.lengths[same])
+    assert float((a.logq[same] - b.logq[same]).abs().max()) <= 2e-5
+    # 3000 states x ~10 arcs: 6 bytes per arc + the beta rows do not fit 160 KiB
+    big = synth.layered_lattice(41, n_states=3000, avg_degree=10.0, vocab=64, width=16, span=6)
+    assert big.n_arcs * 6 + big.n_rows * 12 > 160 * 1024
+    lat = LatticeBatch.from_synth([big], device=dev)
+    K, T = 24, int(lat.depth.max()) + 1
+    u = np.random.default_rng(4).random((1, K, T)).astype(np.float32)
+    for want in (True, False):
+        s = ops.sample_paths(lat, torch.from_numpy(theta), K, max_len=T, uniforms=torch.from_numpy(u), pad=PAD, want_arcs=want)
+        o, sc = oracle_fb(big, theta)
+        ref = O.sample_paths(big.n_rows, big.src, big.label, big.dst, sc, o["logbeta"], u[0].astype(np.float64), PAD)
+        safe = ref["margin"] > 1e-5
+        assert safe.mean() > 0.9
+        assert np.array_equal(s.paths.cpu().numpy()[0][safe], ref["paths"][safe])
+        assert np.array_equal(s.lengths.cpu().numpy()[0][safe], ref["lengths"][safe])
+        if want:
+            assert np.array_equal(s.arcs.cpu().numpy()[0][safe], ref["arcs"][safe])  # (one lattice: arc_off = 0)
+
+
 def test_beta_logits_gather(dev):
     lats = _mixed_batch()[:3]
     K = 4
