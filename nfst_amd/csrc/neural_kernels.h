@@ -63,7 +63,10 @@ __device__ __forceinline__ float neu_scale(int d) { return d > 120 ? 0.0f : __in
 // loads miss to HBM, and a wave's loads complete in order, so they must not sit in front of a
 // computing wave's L2 hits: the last wave of the workgroup stages tile T+1 while the others run
 // phase A of tile T.
-__device__ __forceinline__ void neu_stage_tile(const uint32_t *prog, const int32_t *perm, int F, int T, uint32_t *st, int lane) {
+// (arc_dst given: the destination state of every slot's arc as well, 256 more words -- the gradient kernel's groups need
+// the state their arcs enter before anything else, and that load would otherwise head every group's chain)
+__device__ __forceinline__ void neu_stage_tile(const uint32_t *prog, const int32_t *perm, int F, int T, uint32_t *st, int lane,
+                                               const int32_t *arc_dst = nullptr) {
   const int U = fmt_u(F), ST = fmt_words(F);
   uint32_t *ctl = st, *rec = st + 64;
   int *cas = (int *)(st + 320), *lead = (int *)(st + 576), *nlead = (int *)(st + 640);
@@ -78,7 +81,11 @@ __device__ __forceinline__ void neu_stage_tile(const uint32_t *prog, const int32
     c = prog[(size_t)T * ST + lane];
     for (int j = 0; j < U; ++j) rec[lane + 64 * j] = prog[(size_t)T * ST + 64 + lane + 64 * j];
   }
-  for (int j = 0; j < U; ++j) cas[lane + 64 * j] = perm[(size_t)T * 64 * U + lane + 64 * j];
+  for (int j = 0; j < U; ++j) {
+    const int ca = perm[(size_t)T * 64 * U + lane + 64 * j];
+    cas[lane + 64 * j] = ca;
+    if (arc_dst) ((int *)(st + kNeuStageWords))[lane + 64 * j] = ca >= 0 ? arc_dst[ca] : -1;
+  }
   ctl[lane] = c;
   const uint64_t leaders = __builtin_amdgcn_ballot_w64((c >> 31) != 0);
   if (c >> 31) lead[__builtin_popcountll(leaders & ((1ull << lane) - 1))] = lane;
@@ -514,12 +521,13 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_small(nfst_batc
 // left in its workspace together with beta as (mantissa, exponent) pairs -- p_a is a ratio of such
 // pairs, no float32 log beta in it.  Same phases as the forward kernel: A one wave per group, lanes
 // over H; B eta = Wh^T gamma on float32 MFMA for the states the tile finished.
+constexpr int kNeuGradStageWords = kNeuStageWords + 256;  // ... | destination state of every slot's arc
 struct NeuGradLds {
   int rows, hid;
   __host__ __device__ NeuGradLds(int r, int h) : rows(r), hid(h) {}
   // float2 beta[rows] | float lambda[rows] | two staged tiles | float gamma[32][row_stride]
   __host__ __device__ int64_t bytes() const {
-    return (int64_t)rows * 12 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * NeuLds::row_stride(hid) * 4 + 16;
+    return (int64_t)rows * 12 + 2 * kNeuGradStageWords * 4 + (int64_t)kNeuRows * NeuLds::row_stride(hid) * 4 + 16;
   }
 };
 
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
   float2 *bme = lds;
   float *lam = (float *)(bme + lat.max_rows);
   uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
-  float *gs = (float *)(stage_s + 2 * kNeuStageWords);
+  float *gs = (float *)(stage_s + 2 * kNeuGradStageWords);
   const size_t plane = (size_t)lat.n_lattices * lat.max_rows * hid;
   const float *u_w = ws_fwd + plane + (size_t)b * lat.max_rows * hid;  // u = Wh . beta_hat of the real rows
   const float2 *bme_w = reinterpret_cast<const float2 *>(ws_fwd + 2 * plane) + (size_t)b * lat.max_rows;
@@ -566,15 +574,17 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
   for (int i = tid; i < kNeuRows * hs; i += kNeuThreads) gs[i] = 0.0f;
   __syncthreads();
   if (tid == 0) lam[0] = g_logbeta[m.row_off];
-  if (wv == kNeuWaves - 1 && m.fwd_tiles > 0) neu_stage_tile(prog, perm, F, 0, stage_s, lane);
+  if (wv == kNeuWaves - 1 && m.fwd_tiles > 0) neu_stage_tile(prog, perm, F, 0, stage_s, lane, lat.arc_dst);
   __threadfence_block();
   __syncthreads();
 
   for (int T = 0; T < m.fwd_tiles; ++T) {
-    uint32_t *st = stage_s + (T & 1) * kNeuStageWords;
+    uint32_t *st = stage_s + (T & 1) * kNeuGradStageWords;
     const uint32_t *ctl_s = st, *rec_s = st + 64;
     const int *cas_s = (const int *)(st + 320), *lead_s = (const int *)(st + 576), *nlead_s = (const int *)(st + 640);
-    if (wv == kNeuWaves - 1 && T + 1 < m.fwd_tiles) neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuStageWords, lane);
+    const int *dst_s = (const int *)(st + kNeuStageWords);
+    if (wv == kNeuWaves - 1 && T + 1 < m.fwd_tiles)
+      neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuGradStageWords, lane, lat.arc_dst);
     const int n_lead = nlead_s[0];
 
     // ---- A: one wave per group (a destination state, or a scratch row holding a partial sum)
@@ -591,12 +601,12 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
       for (int q0 = 0; q0 < n_rec; q0 += 64) {
         uint32_t rc_l = 0;
         int ca_l = -1;
-        if (q0 + lane < n_rec) { rc_l = rec_s[l0 * U + q0 + lane]; ca_l = cas_s[l0 * U + q0 + lane]; }
+        int dst_l = 0;
+        if (q0 + lane < n_rec) { rc_l = rec_s[l0 * U + q0 + lane]; ca_l = cas_s[l0 * U + q0 + lane]; dst_l = dst_s[l0 * U + q0 + lane]; }
         const uint64_t real = __builtin_amdgcn_ballot_w64(ca_l >= 0);
         uint64_t todo = real | __builtin_amdgcn_ballot_w64(ca_l < 0 && (int)(rc_l >> 16) == V + 1);
         if (real && !have_d) {  // every real record of a group enters the same state: the row of u and beta
-          const int a0 = __builtin_amdgcn_readlane(ca_l, __builtin_ctzll(real));
-          const int d = lat.arc_dst[a0];
+          const int d = __builtin_amdgcn_readlane(dst_l, __builtin_ctzll(real));  // (staged with the tile)
           bd = bme[d];
 #pragma unroll
           for (int c = 0; c < HC; ++c) ud[c] = u_w[(size_t)d * hid + min(c * 64 + lane, hid - 1)];
@@ -607,83 +617,85 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
         const float x_l = (arc_w && ca_l >= 0) ? arc_w[ca_l] : 0.0f;
         const float2 bs_l = bme[src_l];
         const float lam_l = lam[src_l];
-        // records one after the other, the operand rows of the next one in flight meanwhile
-        struct Ops { float a[HC], bh[HC], et[HC]; int p, ca, lab, src; };
+        // Records go D at a time, the operand rows of all of them requested before the first is used (round 2: one
+        // record after the other with the next one's rows in flight cost a round trip to L2 per record -- 24 of them
+        // for the longest group of a tile).  Straight-line: the row pointers are selected, not the loads (a
+        // conditional load makes the compiler wait for every load in flight where the branches join); a partial-sum
+        // record reads beta_hat / eta of row 0 and ignores them.
+        struct Ops { float a[HC], bh[HC], et[HC]; int p, ca, lab; };
+        constexpr int D = HC <= 2 ? 6 : (HC <= 4 ? 4 : 1);
         auto issue = [&](int p) {
           Ops o;
           o.p = p;
           const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)rc_l, p);
           o.ca = __builtin_amdgcn_readlane(ca_l, p);
-          o.src = (int)((rc & 0xffffu) >> 3);
+          const int src = (int)((rc & 0xffffu) >> 3);
           o.lab = (int)(rc >> 16);
-          if (o.ca >= 0) {
-            const float *pa = label_x + (size_t)o.lab * hid, *pb = bh_in + (size_t)o.src * hid, *pe = eta_w + (size_t)o.src * hid;
+          const bool is_arc = o.ca >= 0;
+          const int srow = is_arc ? src : 0;
+          const float *pa = is_arc ? label_x + (size_t)o.lab * hid : (const float *)gam_row(src);  // (else: gamma of the operand row)
+          const float *pb = bh_in + (size_t)srow * hid, *pe = eta_w + (size_t)srow * hid;
 #pragma unroll
-            for (int c = 0; c < HC; ++c) {
-              const int h = min(c * 64 + lane, hid - 1);
-              o.a[c] = pa[h];
-              o.bh[c] = pb[h];
-              o.et[c] = neu_load_fresh(pe + h);
-            }
-          } else {  // a partial sum: gamma of the operand row
-            const float *pg = gam_row(o.src);
-#pragma unroll
-            for (int c = 0; c < HC; ++c) {
-              o.a[c] = neu_load_fresh(pg + min(c * 64 + lane, hid - 1));
-              o.bh[c] = 0.0f;
-              o.et[c] = 0.0f;
-            }
+          for (int c = 0; c < HC; ++c) {
+            const int h = min(c * 64 + lane, hid - 1);
+            o.a[c] = neu_load_fresh(pa + h);
+            o.bh[c] = pb[h];
+            o.et[c] = neu_load_fresh(pe + h);
           }
           return o;
         };
-        Ops cur;
-        if (todo) { cur = issue(__builtin_ctzll(todo)); todo &= todo - 1; }
-        else continue;
-        constexpr bool kPrefetch = HC <= 4;  // (with 8 components per lane two records' rows do not fit the registers)
-        for (;;) {
-          const bool more = todo != 0;
-          Ops nxt;
-          if (kPrefetch && more) { nxt = issue(__builtin_ctzll(todo)); todo &= todo - 1; }
-          if (cur.ca >= 0) {
-            float t[HC], p1 = 0.0f, p2 = 0.0f;
+        while (todo) {
+          Ops buf[D];
+          int nb = 0, p = 0;
 #pragma unroll
-            for (int c = 0; c < HC; ++c) {
-              const bool in = c * 64 + lane < hid;
-              t[c] = in ? neu_tanh(cur.a[c] + ud[c]) : 0.0f;
-              p1 = fmaf(wl[c], t[c], p1);
-              p2 = fmaf(in ? cur.et[c] : 0.0f, t[c] - (in ? cur.bh[c] : 0.0f), p2);
-            }
-            const float sc = wave_sum(p1), dot = wave_sum(p2);
-            // wave-uniform: p = exp(sc + table weight) beta(d) / beta(s)
-            const float xs = read_lane_f(x_l, cur.p), lam_s = read_lane_f(lam_l, cur.p);
-            const float bsm = read_lane_f(bs_l.x, cur.p);
-            const int bse = __builtin_amdgcn_readlane(__float_as_int(bs_l.y), cur.p);
-            const ME w = exp_split(sc + xs);
-            const float pm = bsm > 0.0f ? w.m * bd.x / bsm : 0.0f;
-            const int pe = w.e + __float_as_int(bd.y) - bse;
-            const float pa = ldexpf(pm, max(min(pe, 64), -300));
-            const float delta = pa * (lam_s + dot);
-            lacc += delta;
-            float *gx = grad_label_x + (size_t)cur.lab * hid;
-#pragma unroll
-            for (int c = 0; c < HC; ++c) {
-              const int h = c * 64 + lane;
-              if (h < hid) {
-                const float tau = fmaf(delta, wl[c], pa * cur.et[c]);
-                const float rho = tau * fmaf(-t[c], t[c], 1.0f);
-                gacc[c] += rho;
-                gw[c] = fmaf(delta, t[c], gw[c]);
-                unsafeAtomicAdd(gx + h, rho);
-              }
-            }
-          } else {
-            lacc += read_lane_f(lam_l, cur.p);
-#pragma unroll
-            for (int c = 0; c < HC; ++c) gacc[c] += (c * 64 + lane < hid) ? cur.a[c] : 0.0f;
+          for (int k = 0; k < D; ++k) {  // past the last record: the last one again, ignored below
+            p = todo ? __builtin_ctzll(todo) : p;
+            nb += todo ? 1 : 0;
+            todo &= todo - (todo ? 1 : 0);
+            buf[k] = issue(p);
           }
-          if (!more) break;
-          if (kPrefetch) cur = nxt;
-          else { cur = issue(__builtin_ctzll(todo)); todo &= todo - 1; }
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            if (k >= nb) continue;
+            const Ops &cur = buf[k];
+            if (cur.ca >= 0) {
+              float t[HC], p1 = 0.0f, p2 = 0.0f;
+#pragma unroll
+              for (int c = 0; c < HC; ++c) {
+                const bool in = c * 64 + lane < hid;
+                t[c] = in ? neu_tanh(cur.a[c] + ud[c]) : 0.0f;
+                p1 = fmaf(wl[c], t[c], p1);
+                p2 = fmaf(in ? cur.et[c] : 0.0f, t[c] - (in ? cur.bh[c] : 0.0f), p2);
+              }
+              const float sc = wave_sum(p1), dot = wave_sum(p2);
+              // wave-uniform: p = exp(sc + table weight) beta(d) / beta(s)
+              const float xs = read_lane_f(x_l, cur.p), lam_s = read_lane_f(lam_l, cur.p);
+              const float bsm = read_lane_f(bs_l.x, cur.p);
+              const int bse = __builtin_amdgcn_readlane(__float_as_int(bs_l.y), cur.p);
+              const ME w = exp_split(sc + xs);
+              const float pm = bsm > 0.0f ? w.m * bd.x / bsm : 0.0f;
+              const int pe = w.e + __float_as_int(bd.y) - bse;
+              const float pa = ldexpf(pm, max(min(pe, 64), -300));
+              const float delta = pa * (lam_s + dot);
+              lacc += delta;
+              float *gx = grad_label_x + (size_t)cur.lab * hid;
+#pragma unroll
+              for (int c = 0; c < HC; ++c) {
+                const int h = c * 64 + lane;
+                if (h < hid) {
+                  const float tau = fmaf(delta, wl[c], pa * cur.et[c]);
+                  const float rho = tau * fmaf(-t[c], t[c], 1.0f);
+                  gacc[c] += rho;
+                  gw[c] = fmaf(delta, t[c], gw[c]);
+                  unsafeAtomicAdd(gx + h, rho);  // (without it: 2.31 / 3.13 / 5.95 ms at H = 8 / 64 / 256 instead of 2.41 / 3.33 / 6.79)
+                }
+              }
+            } else {
+              lacc += read_lane_f(lam_l, cur.p);
+#pragma unroll
+              for (int c = 0; c < HC; ++c) gacc[c] += (c * 64 + lane < hid) ? cur.a[c] : 0.0f;
+            }
+          }
         }
       }
       if (sid < m.n_rows && !continuation) lacc += g_logbeta[m.row_off + sid];
