@@ -570,8 +570,8 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
   // ... and when the caller takes the arcs of the paths (path_arcs), the same 6 bytes per arc hold the arcs' CUMULATIVE
   // probabilities within their state (float) and 16-bit destinations instead: every arc's probability is computed once per
   // block, arc-parallel, and a step is row pointers -> one compare of u against up to 16 cumulative values -> next state; the
-  // labels and the path score are collected in a second pass over the chosen arcs (k_sample 88 -> 59 us at 16 walks per
-  // lattice, 71 us at 64; rocprofv3)
+  // labels and the path score are collected in a second pass over the chosen arcs (k_sample 88 -> 48 us at 16 walks per
+  // lattice, 57 us at 64; rocprofv3)
   const bool precdf = staged && path_arcs != nullptr;
   if (staged) {
     for (int i = tid; i <= m.n_rows; i += nt) rps[i] = rp[i] - m.arc_off;
@@ -626,19 +626,35 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
       if (!__any(active)) break;
       float u = 0.0f;
       int a0 = 0, a1 = 0;
+      if (!uniforms) {
+        // the same numbers as one block per four steps, off the walk's chain: every 64 steps lane r of the walk's 16
+        // takes Philox block t / 4 + r, and a step fetches its uniform from the lane that holds it
+        if ((t & 63) == 0) philox_uniform4(seed, (uint32_t)walk, (uint32_t)((t >> 2) + r), ublk);
+        const float mine = (t & 3) == 0 ? ublk[0] : ((t & 3) == 1 ? ublk[1] : ((t & 3) == 2 ? ublk[2] : ublk[3]));
+        u = __shfl(mine, (t >> 2) & 15, 16);
+      }
       if (active) {
-        if (uniforms) {
-          u = uniforms[walk * max_len + t];
-        } else {
-          if ((t & 3) == 0) philox_uniform4(seed, (uint32_t)walk, (uint32_t)(t >> 2), ublk);
-          u = (t & 3) == 0 ? ublk[0] : ((t & 3) == 1 ? ublk[1] : ((t & 3) == 2 ? ublk[2] : ublk[3]));
-        }
+        if (uniforms) u = uniforms[walk * max_len + t];
         a0 = rps[s];
         a1 = rps[s + 1];
       }
+      // The usual step, without ballots or shuffles: the cumulative values of a state are non-decreasing, so the arc
+      // to take is the one lane of the row with prev <= u < cum (prev: the lane before, DPP); its (index, destination)
+      // reaches the whole row as a row maximum (four DPP steps).  Rows that find none -- more than 16 arcs, or u beyond
+      // the last cumulative value by rounding -- take the chunk loop below.
+      const int i0 = min(a0 + r, max(m.n_arcs - 1, 0));
+      const bool valid0 = active & (a0 + r < a1);
+      const float cum0 = valid0 ? cdf[i0] : 0.0f;
+      const int dv0 = (int)d16[i0];
+      const float prev0 = row_shr_zero<1>(cum0);
+      int key = (valid0 && u < cum0 && !(u < prev0)) ? (((r << 16) | dv0) + 1) : 0;
+      key = max(key, dpp_i<0xB1>(key));
+      key = max(key, dpp_i<0x4E>(key));
+      key = max(key, dpp_i<0x141>(key));
+      key = max(key, dpp_i<0x140>(key));
       float cum_base = 0.0f;
-      int chosen = -1, last = -1, d_ch = 0, d_last = 0;
-      bool more = active & (a0 < a1);
+      int chosen = key ? a0 + ((key - 1) >> 16) : -1, last = -1, d_ch = (key - 1) & 0xffff, d_last = 0;
+      bool more = active & (a0 < a1) & (key == 0);
       for (int c = a0; __any(more); c += 16) {
         const int i = c + r;
         const bool valid = more & (i < a1);
