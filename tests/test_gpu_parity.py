@@ -388,6 +388,35 @@ def test_posterior_sampling_kernel_modes(dev):
             assert np.array_equal(s.arcs.cpu().numpy()[0][safe], ref["arcs"][safe])  # (one lattice: arc_off = 0)
 
 
+@pytest.mark.parametrize("want_arcs", [True, False])
+def test_posterior_sampling_with_table_weights_and_arc_scores(dev, want_arcs):
+    """Weighted tables and caller-supplied per-arc scores enter the arc probabilities (and log q) of the walks."""
+    lats = [synth.layered_lattice(81, n_states=150, avg_degree=6.0, vocab=64, width=6, span=3, weighted=True),
+            synth.layered_lattice(82, n_states=400, avg_degree=10.0, vocab=64, width=12, span=5, weighted=True)]
+    theta = synth.label_scores(13, 64)
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    rng = np.random.default_rng(8)
+    asc = (0.5 * rng.standard_normal(lat.total_arcs)).astype(np.float32)
+    K, T = 64, int(lat.depth.max()) + 1
+    u = rng.random((len(lats), K, T)).astype(np.float32)
+    s = ops.sample_paths(lat, torch.from_numpy(theta), K, arc_scores=torch.from_numpy(asc), max_len=T,
+                         uniforms=torch.from_numpy(u), pad=PAD, want_arcs=want_arcs)
+    for b, l in enumerate(lats):
+        a0 = int(lat.arc_off[b])
+        o, sc = oracle_fb(l, theta, asc[a0:a0 + l.n_arcs])
+        ref = O.sample_paths(l.n_rows, l.src, l.label, l.dst, sc, o["logbeta"], u[b].astype(np.float64), PAD)
+        safe = ref["margin"] > 1e-5
+        assert safe.mean() > 0.95
+        assert np.array_equal(s.paths.cpu().numpy()[b][safe], ref["paths"][safe])
+        assert np.array_equal(s.lengths.cpu().numpy()[b][safe], ref["lengths"][safe])
+        if want_arcs:
+            arcs = s.arcs.cpu().numpy()[b]
+            assert np.array_equal((arcs - np.where(arcs >= 0, a0, 0))[safe], ref["arcs"][safe])
+            for k in np.flatnonzero(safe)[::9]:
+                a = arcs[k, :s.lengths.cpu().numpy()[b, k]] - a0
+                assert abs(sc[a].sum() - o["logZ"] - float(s.logq[b, k])) <= 3e-5
+
+
 def test_beta_logits_gather(dev):
     lats = _mixed_batch()[:3]
     K = 4
