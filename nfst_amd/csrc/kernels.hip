@@ -491,11 +491,29 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
                        (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, beta_hat, ws_fwd, g_log_beta,         \
                        g_beta_hat, gamma, grad_label_x, grad_w, ws);                                               \
   } while (0)
-  if (hid <= 64) NFST_LAUNCH_NEUG(1);
+  // (the packed kernel sums dL/dx per lattice in LDS when [V, hid] floats fit beside its rows and staged tiles)
+  const int64_t lds_small0 = (int64_t)lat->max_rows * 12 + 2 * kNeuGradStageWords * 4 + 16;
+  // (BASELINE batch, whole gradient op: H = 8 1.34 ms with the LDS table against 1.72 with global atomics; H = 16 1.80
+  // against 1.56, H = 32 3.13 against 2.56 -- the table is contended only when its rows are a few lanes wide)
+  const int gx_in_lds = hid <= 8 && lds_small0 + (int64_t)lat->vocab * hid * 4 <= kMaxLds;
+  const int64_t lds_small = lds_small0 + (gx_in_lds ? (int64_t)lat->vocab * hid * 4 : 0);
+#define NFST_LAUNCH_NEUG_SMALL(LPR)                                                                               \
+  do {                                                                                                             \
+    if ((rc = set_lds(k_backward_neural_grad_small<LPR>, lds_small))) return rc;                                   \
+    hipLaunchKernelGGL(k_backward_neural_grad_small<LPR>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds_small, \
+                       (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, beta_hat, ws_fwd, g_log_beta,         \
+                       g_beta_hat, gamma, grad_label_x, grad_w, ws, gx_in_lds);                                    \
+  } while (0)
+  static const int no_small = getenv("NFST_NEU_NO_SMALL") ? 1 : 0;  // (A/B against the two-phase kernel)
+  if (hid <= 8 && !no_small) NFST_LAUNCH_NEUG_SMALL(8);
+  else if (hid <= 16 && !no_small) NFST_LAUNCH_NEUG_SMALL(16);
+  else if (hid <= 32 && !no_small) NFST_LAUNCH_NEUG_SMALL(32);
+  else if (hid <= 64) NFST_LAUNCH_NEUG(1);
   else if (hid <= 128) NFST_LAUNCH_NEUG(2);
   else if (hid <= 256) NFST_LAUNCH_NEUG(4);
   else NFST_LAUNCH_NEUG(8);
 #undef NFST_LAUNCH_NEUG
+#undef NFST_LAUNCH_NEUG_SMALL
   return hip_status(hipGetLastError());
 }
 

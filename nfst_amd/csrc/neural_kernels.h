@@ -727,3 +727,158 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
   for (int c = 0; c < HC; ++c)
     if (c * 64 + lane < hid && gw[c] != 0.0f) unsafeAtomicAdd(grad_w + c * 64 + lane, gw[c]);
 }
+
+// Small hidden sizes (hid <= LPR <= 32; round 2): the packed layout of k_backward_neural_small for the gradient.  A wave
+// holds 64 / LPR records side by side (LPR lanes each), D per slot with all operand rows requested up front; every slot
+// keeps its own sums (lambda, gamma, dL/dW), merged once per group; eta = Wh^T gamma of the finished state is taken by
+// the same wave (row h of Wh^T in lane h's registers, gamma[j] by v_readlane): no second phase, one barrier per tile.
+template <int LPR>
+__global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad_small(
+    nfst_batch lat, const float *__restrict__ label_x, const float *__restrict__ whT, const float *__restrict__ wvec, int hid,
+    const float *__restrict__ beta_hat, const float *__restrict__ ws_fwd, const float *__restrict__ g_logbeta,
+    const float *__restrict__ g_betahat, float *gamma, float *grad_label_x, float *grad_w, float *ws, int gx_in_lds) {
+  extern __shared__ float2 lds[];
+  constexpr int RPB = 64 / LPR, D = 4;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane / LPR, h = lane % LPR;
+  const bool hv = h < hid;
+  const int hc = min(h, hid - 1);
+  const Meta m = load_meta(lat.meta, b);
+  float2 *bme = lds;
+  float *lam = (float *)(bme + lat.max_rows);
+  uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
+  // dL/dx of this lattice is summed in LDS when [V, hid] floats fit (gx_in_lds) and added to the global table once at
+  // the end: at H = 8 the whole batch's atomics would otherwise land on 64 cache lines
+  float *gx_s = (float *)(stage_s + 2 * kNeuGradStageWords);
+  const size_t plane = (size_t)lat.n_lattices * lat.max_rows * hid;
+  const float *u_w = ws_fwd + plane + (size_t)b * lat.max_rows * hid;
+  const float2 *bme_w = reinterpret_cast<const float2 *>(ws_fwd + 2 * plane) + (size_t)b * lat.max_rows;
+  float *gam_w = ws + (size_t)b * lat.max_rows * hid;
+  float *eta_w = ws + plane + (size_t)b * lat.max_rows * hid;
+  float *gam_out = gamma + (size_t)m.row_off * hid;
+  const float *bh_in = beta_hat + (size_t)m.row_off * hid;
+  auto gam_row = [&](int r) { return r < m.n_rows ? gam_out + (size_t)r * hid : gam_w + (size_t)r * hid; };
+  const int F = m.fwd_u, U = fmt_u(F);
+  const uint32_t *prog = lat.fwd_stream + m.fwd_off;
+  const int32_t *perm = lat.fwd_perm + m.fwd_slot_off;
+  const float *arc_w = lat.weighted ? lat.arc_w : nullptr;
+  const int V = lat.vocab;
+
+  for (int i = tid; i < lat.max_rows; i += kNeuThreads) {
+    bme[i] = i < m.n_rows ? bme_w[i] : make_float2(0.0f, __int_as_float(kEZero));
+    lam[i] = 0.0f;
+  }
+  if (gx_in_lds) for (int i = tid; i < V * hid; i += kNeuThreads) gx_s[i] = 0.0f;
+  for (int i = tid; i < hid; i += kNeuThreads) eta_w[i] = g_betahat ? g_betahat[(size_t)m.row_off * hid + i] : 0.0f;
+  const float wl = hv ? wvec[h] : 0.0f;
+  float whr[LPR];  // row h of Wh^T
+#pragma unroll
+  for (int j = 0; j < LPR; ++j) whr[j] = (hv && j < hid) ? whT[(size_t)h * hid + j] : 0.0f;
+  float gw = 0.0f;
+  __syncthreads();
+  if (tid == 0) lam[0] = g_logbeta[m.row_off];
+  if (wv == kNeuWaves - 1 && m.fwd_tiles > 0) neu_stage_tile(prog, perm, F, 0, stage_s, lane, lat.arc_dst);
+  __threadfence_block();
+  __syncthreads();
+
+  for (int T = 0; T < m.fwd_tiles; ++T) {
+    uint32_t *st = stage_s + (T & 1) * kNeuGradStageWords;
+    const uint32_t *ctl_s = st, *rec_s = st + 64;
+    const int *cas_s = (const int *)(st + 320), *lead_s = (const int *)(st + 576), *nlead_s = (const int *)(st + 640);
+    const int *dst_s = (const int *)(st + kNeuStageWords);
+    if (wv == kNeuWaves - 1 && T + 1 < m.fwd_tiles)
+      neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuGradStageWords, lane, lat.arc_dst);
+    const int n_lead = nlead_s[0];
+    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+      const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
+      const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
+      const bool continuation = (c0 >> 30) & 1u;
+      // the state the group's arcs enter (all the same): its u row and beta
+      int d = -1;
+      for (int q0 = 0; q0 < n_rec && d < 0; q0 += 64) {
+        const int dl = q0 + lane < n_rec ? dst_s[l0 * U + q0 + lane] : -1;
+        const uint64_t real = __builtin_amdgcn_ballot_w64(dl >= 0);
+        if (real) d = __builtin_amdgcn_readlane(dl, __builtin_ctzll(real));
+      }
+      const float ud = d >= 0 ? u_w[(size_t)d * hid + hc] : 0.0f;
+      const float2 bd = d >= 0 ? bme[d] : make_float2(0.0f, __int_as_float(kEZero));
+      float lacc = 0.0f, gacc = 0.0f;
+      for (int q0 = 0; q0 < n_rec; q0 += D * RPB) {
+        float a[D], bh[D], et[D], x[D], lm[D];
+        float2 bs[D];
+        bool isarc[D], act[D];
+        int lab[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {  // (straight-line: a slot past the group's records reads row 0 and counts for nothing)
+          const int q = q0 + k * RPB + sub;
+          const bool in = q < n_rec;
+          const uint32_t rc = in ? rec_s[l0 * U + q] : 0u;
+          const int ca = in ? cas_s[l0 * U + q] : -1;
+          const int src = (int)((rc & 0xffffu) >> 3);
+          lab[k] = (int)(rc >> 16);
+          isarc[k] = ca >= 0;
+          act[k] = isarc[k] || lab[k] == V + 1;
+          const int srow = isarc[k] ? src : 0;
+          const float *pa = isarc[k] ? label_x + (size_t)lab[k] * hid : (const float *)gam_row(src);
+          a[k] = neu_load_fresh(pa + hc);
+          bh[k] = bh_in[(size_t)srow * hid + hc];
+          et[k] = neu_load_fresh(eta_w + (size_t)srow * hid + hc);
+          x[k] = arc_w ? arc_w[max(ca, 0)] : 0.0f;
+          bs[k] = bme[src];
+          lm[k] = lam[src];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float t = hv ? neu_tanh(a[k] + ud) : 0.0f;
+          const float sc = neu_group_sum<LPR>(wl * t);
+          const float dot = neu_group_sum<LPR>(hv ? et[k] * (t - bh[k]) : 0.0f);
+          const ME w = exp_split_nb(sc + x[k]);
+          const float pm = bs[k].x > 0.0f ? w.m * bd.x / bs[k].x : 0.0f;
+          const int pe = w.e + __float_as_int(bd.y) - __float_as_int(bs[k].y);
+          const float pa = ldexpf(pm, max(min(pe, 64), -300));
+          const float delta = pa * (lm[k] + dot);
+          if (isarc[k]) {
+            lacc += delta;
+            if (hv) {
+              const float tau = fmaf(delta, wl, pa * et[k]);
+              const float rho = tau * fmaf(-t, t, 1.0f);
+              gacc += rho;
+              gw = fmaf(delta, t, gw);
+              if (gx_in_lds) atomicAdd(gx_s + lab[k] * hid + h, rho);
+              else unsafeAtomicAdd(grad_label_x + (size_t)lab[k] * hid + h, rho);
+            }
+          } else if (act[k]) {  // a partial sum: lambda and gamma of the operand row
+            lacc += lm[k];
+            gacc += hv ? a[k] : 0.0f;
+          }
+        }
+      }
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {  // merge the record slots
+        lacc += __shfl_xor(lacc, off);
+        gacc += __shfl_xor(gacc, off);
+      }
+      if (sid < m.n_rows && !continuation) lacc += g_logbeta[m.row_off + sid];
+      float eta = 0.0f;
+#pragma unroll
+      for (int j = 0; j < LPR; ++j) eta = fmaf(whr[j], read_lane_f(gacc, j), eta);
+      if (sub == 0 && hv) {
+        gam_row(sid)[h] = gacc;
+        if (sid < m.n_rows)
+          eta_w[(size_t)sid * hid + h] = eta + (g_betahat ? g_betahat[((size_t)m.row_off + sid) * hid + h] : 0.0f);
+      }
+      if (lane == 0) lam[sid] = lacc;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (gx_in_lds)
+    for (int i = tid; i < V * hid; i += kNeuThreads)
+      if (gx_s[i] != 0.0f) unsafeAtomicAdd(grad_label_x + i, gx_s[i]);
+  // dL/dW: the slots of a wave first, then one atomic add per wave and component
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) gw += __shfl_xor(gw, off);
+  if (sub == 0 && hv && gw != 0.0f) unsafeAtomicAdd(grad_w + h, gw);
+}
