@@ -426,9 +426,21 @@ class _NeuralBeta(torch.autograd.Function):
                                             beta_hat.data_ptr(), ws_fwd.data_ptr(), g_lb.data_ptr(),
                                             0 if g_bh is None else g_bh.data_ptr(), gamma.data_ptr(), g_x.data_ptr(),
                                             g_w.data_ptr(), ws.data_ptr(), _stream()), "nfst_backward_neural_grad")
-        # dL/dWh[i, j] = sum over states of gamma(s)[i] beta_hat(s)[j]: one library GEMM
-        g_wh = gamma.t() @ beta_hat
-        return None, g_x, g_wh, g_w
+        # dL/dWh[i, j] = sum over states of gamma(s)[i] beta_hat(s)[j]: a library GEMM
+        return None, g_x, _gram(gamma, beta_hat), g_w
+
+
+def _gram(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T b for tall, narrow a and b ([n, H], n ~ 5e5): as one GEMM with K = n the library takes 0.3 ms at
+    H = 8 ... 1.25 ms at H = 256 on the BASELINE batch's rows; 256 row chunks as one batched GEMM and a sum take
+    0.04 ... 0.54 ms (`profiles/tune/gemm_tall_skinny.py`) and add in a better order."""
+    n, H = a.shape
+    chunks = 256 if n >= 256 * 64 else 1
+    m = (n // chunks) * chunks
+    out = torch.bmm(a[:m].view(chunks, -1, H).transpose(1, 2), b[:m].view(chunks, -1, H)).sum(0)
+    if m < n:
+        out = out + a[m:].t() @ b[m:]
+    return out
 
 
 def backward_neural(lat: LatticeBatch, emb: torch.Tensor, Wx: torch.Tensor, Wh: torch.Tensor, W: torch.Tensor,
