@@ -469,6 +469,14 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   return hip_status(hipGetLastError());
 }
 
+#ifdef NFST_NEU_STAMPS
+extern "C" int nfst_debug_neu_stamps(unsigned long long *out, int reset) {  // profiling build only
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(neu_stamps), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(neu_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
 int64_t nfst_neural_grad_ws_floats(const nfst_batch *lat, int32_t hid) {
   if (!lat || hid <= 0) return NFST_ERR_ARG;
   return 2 * (int64_t)lat->n_lattices * lat->max_rows * hid;
@@ -492,7 +500,7 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
                        g_beta_hat, gamma, grad_label_x, grad_w, ws);                                               \
   } while (0)
   // (the packed kernel sums dL/dx per lattice in LDS when [V, hid] floats fit beside its rows and staged tiles)
-  const int64_t lds_small0 = (int64_t)lat->max_rows * 12 + 2 * kNeuGradStageWords * 4 + 16;
+  const int64_t lds_small0 = (int64_t)neu_rows_al(lat->max_rows) * 8 + (int64_t)((lat->max_rows + 3) & ~3) * 4 + 2 * kNeuGradStageWords * 4 + 16;
   // (BASELINE batch, whole gradient op: H = 8 1.34 ms with the LDS table against 1.72 with global atomics; H = 16 1.80
   // against 1.56, H = 32 3.13 against 2.56 -- the table is contended only when its rows are a few lanes wide)
   const int gx_in_lds = hid <= 8 && lds_small0 + (int64_t)lat->vocab * hid * 4 <= kMaxLds;

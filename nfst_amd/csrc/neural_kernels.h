@@ -26,16 +26,47 @@
 // by weight.
 #pragma once
 
+#ifdef NFST_NEU_STAMPS
+// (profiling build only: per-wave busy time of phase A, and where a tile's time goes, for workgroup 0; 100 MHz ticks)
+__device__ unsigned long long neu_stamps[128];
+#define NEU_STAMP_ADD(i, v) do { if (b == 0 && lane == 0) atomicAdd(&neu_stamps[i], (unsigned long long)(v)); } while (0)
+#define NEU_NOW() wall_clock64()
+#else
+#define NEU_STAMP_ADD(i, v) do {} while (0)
+#define NEU_NOW() 0ull
+#endif
 constexpr int kNeuThreads = 1024, kNeuWaves = kNeuThreads / 64, kNeuRows = 32, kNeuMaxHid = 512;
 constexpr int kNeuStageWords = 64 + 256 + 256 + 64 + 4;  // ctl | rec | slot -> arc | leaders | their count
 
+// Which group of a tile a wave takes first.  The packer lists a level's states by falling degree, so group 0 is the
+// largest; wave w sits on SIMD w % 4 and SIMD 3 also hosts the (light) staging wave.  With group i on wave i SIMD 0 gets
+// ranks 0, 4, 8, 12 -- the heaviest of every four -- and its waves end phase A last (in-kernel stamps at H = 256: 10.0 us
+// for wave 0 against 5.6 for wave 3).  This order deals the ranks to the SIMDs like a snake, the largest group to SIMD 3:
+// SIMD 3 <- 0, 7, 8; SIMD 0 <- 1, 6, 9, 14; SIMD 1 <- 2, 5, 10, 13; SIMD 2 <- 3, 4, 11, 12.  Later rounds (tiles with more
+// than 15 groups): group 15 r + w.
+__device__ __forceinline__ int neu_first_group(int wv) { return (int)((0xfcde8ba974560321ull >> (4 * wv)) & 15u); }
+// Tiles with more than 15 groups (about half of them on the BASELINE batch: 14.6 groups on average): groups 15 .. 30 go
+// to the staging wave first -- it is idle for most of the phase -- then to the waves in rising order of what they already
+// hold: 15 + k on wave {15, 12, 13, 14, 11, 8, 9, 10, 7, 4, 5, 6, 3, 0, 1, 2}[k] (with group 15 r + w on wave w, wave 0 had
+// two groups in every such tile and ended phase A 1.7 us after the wave with the largest group).  Groups from 31 on:
+// 31 + 15 (round - 2) + w on waves 0 .. 14.
+__device__ __forceinline__ int neu_group_of(int wv, int rnd) {
+  if (rnd == 0) return wv < 15 ? neu_first_group(wv) : (1 << 20);
+  if (rnd == 1) return 15 + (int)((0x032147658ba9cfedull >> (4 * wv)) & 15u);
+  return wv < 15 ? 31 + (rnd - 2) * 15 + wv : (1 << 20);
+}
+
+// The (mantissa, exponent) rows come first in LDS, 8 bytes each: an odd row count would leave everything behind them
+// -- the rows phase B reads 16 bytes at a time -- 8 bytes off, and a ds_read_b128 off its alignment is replayed at 64
+// cycles per wave instruction (the BASELINE batch has 2221 rows: phase B took 8 us per tile instead of 4)
+__host__ __device__ inline int neu_rows_al(int rows) { return (rows + 1) & ~1; }
 struct NeuLds {
   int rows, hid;
   __host__ __device__ NeuLds(int r, int h) : rows(r), hid(h) {}
   // multiple of 16 (the K loop of phase B) + 4 floats so that the 16 rows of a pass start in different banks
   __host__ __device__ static int row_stride(int h) { return ((h + 15) & ~15) + 4; }
   // float2 beta[rows] | two staged tiles | float bh[32][row_stride]
-  __host__ __device__ int64_t bytes() const { return (int64_t)rows * 8 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
+  __host__ __device__ int64_t bytes() const { return (int64_t)neu_rows_al(rows) * 8 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
 };
 
 // tanh(x) = 1 - 2 / (e^2x + 1) on the hardware exp2 and reciprocal: absolute error below 2e-7 over
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
   float2 *bme = lds;
-  uint32_t *stage_s = (uint32_t *)(bme + lat.max_rows);  // two tiles: kNeuStageWords each
+  uint32_t *stage_s = (uint32_t *)(bme + neu_rows_al(lat.max_rows));  // two tiles: kNeuStageWords each
   float *bh_s = (float *)(stage_s + 2 * kNeuStageWords);
   // beta_hat of a real row lives in the output array, that of a scratch row (partial groups of the
   // tile program) in the workspace; u = Wh . beta_hat of the real rows in the workspace
@@ -218,16 +249,21 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   if (wv == kNeuWaves - 1 && m.bwd_tiles > 0) stage_tile(0, stage_s);
   __syncthreads();
 
+#ifdef NFST_NEU_STAMPS
+  unsigned long long st_own = 0, st_bar1 = 0, st_b = 0, st_fence = 0, st_bar2 = 0, st_tiles = 0;
+#endif
   for (int T = 0; T < m.bwd_tiles; ++T) {
     uint32_t *st = stage_s + (T & 1) * kNeuStageWords;
     const uint32_t *ctl_s = st, *rec_s = st + 64;
     const int *cas_s = (const int *)(st + 320), *lead_s = (const int *)(st + 576), *nlead_s = (const int *)(st + 640);
+    const unsigned long long t_tile = NEU_NOW();
+    (void)t_tile;
     if (wv == kNeuWaves - 1 && T + 1 < m.bwd_tiles) stage_tile(T + 1, stage_s + ((T + 1) & 1) * kNeuStageWords);
     const int n_lead = nlead_s[0];
 
     // ---- A: one wave per group.  The operands of the group's next record are in flight while
     // the current one is computed (they come from L2: label table, u and beta_hat rows).
-    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+    for (int rnd = (wv == kNeuWaves - 1), i = neu_group_of(wv, rnd); i < n_lead; ++rnd, i = neu_group_of(wv, rnd)) {
       const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
       const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
@@ -338,15 +374,32 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
       }
       if (lane == 0) bme[sid] = me_pack(macc, eacc);
     }
+    const unsigned long long t_own = NEU_NOW();
     __syncthreads();
+    const unsigned long long t_a = NEU_NOW();
+#ifdef NFST_NEU_STAMPS
+    st_own += t_own - t_tile; st_bar1 += t_a - t_own;
+#endif
+    (void)t_own;
 
     // ---- B: u = Wh . beta_hat for the states this tile wrote (real rows only)
     neu_phase_b(bh_s, hs, n_lead, wh, hid, ctl_s, lead_s, tid, wv, lane,
                 [&](int sid) { return (const float *)bh_row(sid); },
                 [&](int sid, int col, float v) { if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = v; });
+    const unsigned long long t_b = NEU_NOW();
     __threadfence_block();
+    const unsigned long long t_f = NEU_NOW();
     __syncthreads();
+#ifdef NFST_NEU_STAMPS
+    st_b += t_b - t_a; st_fence += t_f - t_b; st_bar2 += NEU_NOW() - t_f; st_tiles += 1;
+#endif
+    (void)t_b; (void)t_f; (void)t_a;
   }
+#ifdef NFST_NEU_STAMPS
+  // per wave of workgroup 0: own phase A | wait at its barrier | phase B | fence | wait at the tile's last barrier | tiles
+  NEU_STAMP_ADD(wv * 8 + 0, st_own); NEU_STAMP_ADD(wv * 8 + 1, st_bar1); NEU_STAMP_ADD(wv * 8 + 2, st_b);
+  NEU_STAMP_ADD(wv * 8 + 3, st_fence); NEU_STAMP_ADD(wv * 8 + 4, st_bar2); NEU_STAMP_ADD(wv * 8 + 5, st_tiles);
+#endif
 
   // ---- outputs: log beta; beta_hat is in place (rows the program never wrote: -inf, 0)
   float2 *bme_w = reinterpret_cast<float2 *>(ws + 2 * (size_t)lat.n_lattices * lat.max_rows * hid) + (size_t)b * lat.max_rows;
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_small(nfst_batc
   const int hc = min(h, hid - 1);
   const Meta m = load_meta(lat.meta, b);
   float2 *bme = lds;
-  uint32_t *stage_s = (uint32_t *)(bme + lat.max_rows);
+  uint32_t *stage_s = (uint32_t *)(bme + neu_rows_al(lat.max_rows));
   float *bh_w = ws + (size_t)b * lat.max_rows * hid;
   float *u_w = ws + ((size_t)lat.n_lattices + b) * lat.max_rows * hid;
   float *bh_out = beta_hat + (size_t)m.row_off * hid;
@@ -429,7 +482,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_small(nfst_batc
     if (wv == kNeuWaves - 1 && T + 1 < m.bwd_tiles)
       neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuStageWords, lane);
     const int n_lead = nlead_s[0];
-    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+    for (int rnd = (wv == kNeuWaves - 1), i = neu_group_of(wv, rnd); i < n_lead; ++rnd, i = neu_group_of(wv, rnd)) {
       const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
       const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
@@ -527,7 +580,7 @@ struct NeuGradLds {
   __host__ __device__ NeuGradLds(int r, int h) : rows(r), hid(h) {}
   // float2 beta[rows] | float lambda[rows] | two staged tiles | float gamma[32][row_stride]
   __host__ __device__ int64_t bytes() const {
-    return (int64_t)rows * 12 + 2 * kNeuGradStageWords * 4 + (int64_t)kNeuRows * NeuLds::row_stride(hid) * 4 + 16;
+    return (int64_t)neu_rows_al(rows) * 8 + (int64_t)((rows + 3) & ~3) * 4 + 2 * kNeuGradStageWords * 4 + (int64_t)kNeuRows * NeuLds::row_stride(hid) * 4 + 16;
   }
 };
 
@@ -541,7 +594,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
   float2 *bme = lds;
-  float *lam = (float *)(bme + lat.max_rows);
+  float *lam = (float *)(bme + neu_rows_al(lat.max_rows));
   uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
   float *gs = (float *)(stage_s + 2 * kNeuGradStageWords);
   const size_t plane = (size_t)lat.n_lattices * lat.max_rows * hid;
@@ -588,7 +641,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
     const int n_lead = nlead_s[0];
 
     // ---- A: one wave per group (a destination state, or a scratch row holding a partial sum)
-    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+    for (int rnd = (wv == kNeuWaves - 1), i = neu_group_of(wv, rnd); i < n_lead; ++rnd, i = neu_group_of(wv, rnd)) {
       const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
       const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
@@ -746,7 +799,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad_small(
   const int hc = min(h, hid - 1);
   const Meta m = load_meta(lat.meta, b);
   float2 *bme = lds;
-  float *lam = (float *)(bme + lat.max_rows);
+  float *lam = (float *)(bme + neu_rows_al(lat.max_rows));
   uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
   // dL/dx of this lattice is summed in LDS when [V, hid] floats fit (gx_in_lds) and added to the global table once at
   // the end: at H = 8 the whole batch's atomics would otherwise land on 64 cache lines
@@ -790,7 +843,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad_small(
     if (wv == kNeuWaves - 1 && T + 1 < m.fwd_tiles)
       neu_stage_tile(prog, perm, F, T + 1, stage_s + ((T + 1) & 1) * kNeuGradStageWords, lane, lat.arc_dst);
     const int n_lead = nlead_s[0];
-    for (int i = wv; i < n_lead && wv < kNeuWaves - 1; i += kNeuWaves - 1) {
+    for (int rnd = (wv == kNeuWaves - 1), i = neu_group_of(wv, rnd); i < n_lead; ++rnd, i = neu_group_of(wv, rnd)) {
       const int l0 = __builtin_amdgcn_readfirstlane(lead_s[i]);
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(ctl_s[l0]);
       const int sid = (int)((c0 & 0xffffu) >> 3), n_rec = (1 << ((c0 >> 20) & 7u)) * U;
