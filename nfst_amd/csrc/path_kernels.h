@@ -693,14 +693,14 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
     // (the arcs were stored by lane 0 of this same 16-lane group: a workgroup-scope fence is all the order needed -- an
     // agent-scope one writes the XCD's L2 back, once per wave: 100 us)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    float part = 0.0f;
+    // (in float64: a path of a thousand arcs sums to several thousand, log q is what is left after log Z is taken off)
+    double part = 0.0;
     for (int j = r; j < t; j += 16) {
       const int a = __hip_atomic_load(outa + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const int lab = lat.arc_l16[a];
-      float x = tl[lab];
-      if (arc_w) x += arc_w[a];
-      if (sc.arc_scores) x += sc.arc_scores[a];
-      part += x;
+      part += (double)tl[lab];
+      if (arc_w) part += (double)arc_w[a];
+      if (sc.arc_scores) part += (double)sc.arc_scores[a];
       out[j] = lab;
     }
     part += __shfl_xor(part, 8, 16);
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
     part += __shfl_xor(part, 1, 16);
     if (r == 0) {
       lengths[walk] = ok ? t : -1;
-      logq[walk] = ok ? (float)((double)part - logz64[b]) : kNegInf;
+      logq[walk] = ok ? (float)(part - logz64[b]) : kNegInf;
     }
     for (int j = t + r; j < max_len; j += 16) { out[j] = pad; outa[j] = -1; }
     return;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
   int32_t *out = paths + walk * max_len;
   int32_t *outa = path_arcs ? path_arcs + walk * max_len : nullptr;
   int s = 0, t = 0;
-  float tot = 0.0f;
+  double tot = 0.0;  // (float64: see the second pass of the precomputed mode)
   float ublk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   bool ok = true;
   bool active = live;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
           out[t] = staged ? lbs[chosen - m.arc_off] : lat.arc_l16[chosen];
           if (outa) outa[t] = chosen;
         }
-        tot += sc_ch;
+        tot += (double)sc_ch;
         s = d_ch;
         ++t;
       }
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(1024) void k_sample(nfst_batch lat, nfst_scores sc,
   if (!ok && r == 0) atomicExch(status, NFST_ERR_LENGTH);
   if (r == 0) {
     lengths[walk] = ok ? t : -1;
-    logq[walk] = ok ? (float)((double)tot - logz64[b]) : kNegInf;
+    logq[walk] = ok ? (float)(tot - logz64[b]) : kNegInf;
   }
   for (int j = t + r; j < max_len; j += 16) { out[j] = pad; if (outa) outa[j] = -1; }
 }
