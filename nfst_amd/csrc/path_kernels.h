@@ -830,16 +830,16 @@ __global__ __launch_bounds__(64) void k_score_paths(nfst_batch lat, nfst_scores 
   const size_t walk = (size_t)b * K + k;
   const int32_t *mk = marks + walk * max_len;
   int s = 0;
-  float tot = 0.0f;
+  double tot = 0.0;  // (float64 sum, rounded once: a float32 sum of a thousand arcs loses 1e-3)
   for (int t = 0; t < max_len; ++t) {
     const int l = mk[t];
     const int a = (l >= 0 && l < lat.vocab) ? find_arc(lat.arc_label, rp[s], rp[s + 1], l) : -1;
-    if (a < 0) { tot = kNegInf; s = 0; break; }
+    if (a < 0) { tot = (double)kNegInf; s = 0; break; }
     const int d = lat.arc_dst[a];
-    if (d != s) tot += arc_score(theta, arc_w, sc.arc_scores, l, a);
+    if (d != s) tot += (double)arc_score(theta, arc_w, sc.arc_scores, l, a);
     s = d;
   }
-  path_score[walk] = tot;
+  path_score[walk] = (float)tot;
   end_state[walk] = s;
 }
 
