@@ -432,7 +432,8 @@ int nfst_proposal_step_backward(const nfst_batch *lat, const int64_t *value_stat
 
 int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid) {
   if (!lat || hid <= 0) return NFST_ERR_ARG;
-  return 2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1);
+  // u and beta_hat planes, (mantissa, exponent) rows, and Wh in MFMA fragment order (k_pack_mfma_b)
+  return neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1)) + (int64_t)hid * hid;
 }
 
 int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh, const float *w, int32_t hid,
@@ -442,11 +443,17 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   if (!label_x || !wh || !w || !log_beta || !beta_hat || !ws || hid <= 0) return NFST_ERR_ARG;
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   const int64_t lds = NeuLds(lat->max_rows, hid).bytes();
+  // phase B reads Wh in MFMA fragment order when hid is a multiple of 64 (NFST_NEU_PACK=0: from the matrix itself)
+  static const int pack_off = getenv("NFST_NEU_PACK") && getenv("NFST_NEU_PACK")[0] == '0';
+  const int wh_packed = !pack_off && hid % 64 == 0;
+  if (wh_packed)
+    hipLaunchKernelGGL(k_pack_mfma_b, dim3((hid * hid / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh, (int)hid,
+                       reinterpret_cast<float4 *>(ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1))));
 #define NFST_LAUNCH_NEU(HC)                                                                                   \
   do {                                                                                                        \
     if ((rc = set_lds(k_backward_neural<HC>, lds))) return rc;                                                \
     hipLaunchKernelGGL(k_backward_neural<HC>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,          \
-                       (hipStream_t)stream, *lat, label_x, wh, w, (int)hid, log_beta, beta_hat, ws);        \
+                       (hipStream_t)stream, *lat, label_x, wh, w, (int)hid, log_beta, beta_hat, ws, wh_packed); \
   } while (0)
 #define NFST_LAUNCH_NEU_SMALL(LPR)                                                                             \
   do {                                                                                                        \
@@ -479,7 +486,7 @@ extern "C" int nfst_debug_neu_stamps(unsigned long long *out, int reset) {  // p
 
 int64_t nfst_neural_grad_ws_floats(const nfst_batch *lat, int32_t hid) {
   if (!lat || hid <= 0) return NFST_ERR_ARG;
-  return 2 * (int64_t)lat->n_lattices * lat->max_rows * hid;
+  return neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid) + (int64_t)hid * hid;  // ... + Wh^T in fragment order
 }
 
 int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w, int32_t hid,
@@ -492,12 +499,17 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   if (lat->fwd_slots > 0 && !lat->fwd_perm) return NFST_ERR_ARG;
   const int64_t lds = NeuGradLds(lat->max_rows, hid).bytes();
+  static const int pack_off = getenv("NFST_NEU_PACK") && getenv("NFST_NEU_PACK")[0] == '0';
+  const int wh_packed = !pack_off && hid % 64 == 0;
+  if (wh_packed)
+    hipLaunchKernelGGL(k_pack_mfma_b, dim3((hid * hid / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh_t, (int)hid,
+                       reinterpret_cast<float4 *>(ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid)));
 #define NFST_LAUNCH_NEUG(HC)                                                                                       \
   do {                                                                                                             \
     if ((rc = set_lds(k_backward_neural_grad<HC>, lds))) return rc;                                                \
     hipLaunchKernelGGL(k_backward_neural_grad<HC>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,          \
                        (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, beta_hat, ws_fwd, g_log_beta,         \
-                       g_beta_hat, gamma, grad_label_x, grad_w, ws);                                               \
+                       g_beta_hat, gamma, grad_label_x, grad_w, ws, wh_packed);                                    \
   } while (0)
   // (the packed kernel sums dL/dx per lattice in LDS when [V, hid] floats fit beside its rows and staged tiles)
   const int64_t lds_small0 = (int64_t)neu_rows_al(lat->max_rows) * 8 + (int64_t)((lat->max_rows + 3) & ~3) * 4 + 2 * kNeuGradStageWords * 4 + 16;

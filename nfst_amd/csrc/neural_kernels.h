@@ -137,7 +137,7 @@ __device__ __forceinline__ float neu_load_fresh(const float *p) {
 template <class RowOf, class Put>
 __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, const float *__restrict__ wh, int hid,
                                             const uint32_t *ctl_s, const int *lead_s, int tid, int wv, int lane,
-                                            RowOf row_of, Put put) {
+                                            RowOf row_of, Put put, const float4 *whp = nullptr) {
   // ---- B: u = Wh . beta_hat for the states this tile wrote, 16 of them per pass over Wh:
   // D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32, one block of
   // 16 columns per wave.  A comes from the LDS rows phase A filled, B straight from Wh (L2).
@@ -162,11 +162,16 @@ __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, c
       if ((hid & 15) == 0) {
         const float *bp = wh + (size_t)col * hid + 4 * kq;
         const float *ap = rows + li * hs + 4 * kq;
+        // B fragments: from the matrix itself (16 rows x 64 bytes per load instruction), or, when the launcher packed it
+        // (hid a multiple of 64, k_pack_mfma_b), from a copy laid out in fragment order -- one load instruction = 1 KiB of
+        // consecutive bytes.  Fragment-shaped loads queue in the load path: 7-8 us per tile at H = 256.
+        const float4 *b4 = whp ? whp + (size_t)ct * (hid >> 6) * 256 + lane : reinterpret_cast<const float4 *>(bp);
+        const int sd = whp ? 64 : 4, sh = whp ? 256 : 16;  // float4 strides per d and per 64 of K
         int h = 0;
         for (; h + 64 <= hid; h += 64) {  // four 16-byte loads of Wh in flight per lane
           float4 bq[4], aq[4];
 #pragma unroll
-          for (int d = 0; d < 4; ++d) bq[d] = *reinterpret_cast<const float4 *>(bp + h + 16 * d);
+          for (int d = 0; d < 4; ++d) bq[d] = b4[(h >> 6) * sh + d * sd];
 #pragma unroll
           for (int d = 0; d < 4; ++d) aq[d] = *reinterpret_cast<const float4 *>(ap + h + 16 * d);
 #pragma unroll
@@ -203,16 +208,31 @@ __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, c
   }
 }
 
+// The matrix of phase B in MFMA fragment order (hid a multiple of 64): float4 number ((ct * hid/64 + c) * 4 + d) * 64 + lane
+// holds M[16 ct + (lane & 15)][64 c + 16 d + 4 (lane >> 4) + 0 .. 3], what lane `lane` of the wave with column block ct
+// loads at step c, d of its K loop.  One thread per float4; 256 KiB at H = 256, once per launch.
+__global__ __launch_bounds__(256) void k_pack_mfma_b(const float *__restrict__ mat, int hid, float4 *__restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= hid * hid / 4) return;
+  const int lane = t & 63, d = (t >> 6) & 3, cc = t >> 8, nch = hid >> 6;
+  const int c = cc % nch, ct = cc / nch;
+  const float *p = mat + (size_t)(ct * 16 + (lane & 15)) * hid + c * 64 + 16 * d + 4 * (lane >> 4);
+  out[t] = make_float4(p[0], p[1], p[2], p[3]);
+}
+// where the packed copy sits in a workspace of `used` floats (16-byte aligned)
+__host__ __device__ inline int64_t neu_pack_off(int64_t used) { return (used + 3) & ~(int64_t)3; }
+
 template <int HC>  // components per lane: hid <= 64 * HC
 __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat, const float *__restrict__ label_x,
                                                                  const float *__restrict__ wh,
                                                                  const float *__restrict__ wvec, int hid,
                                                                  float *__restrict__ log_beta,
-                                                                 float *beta_hat, float *ws) {
+                                                                 float *beta_hat, float *ws, int wh_packed) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
+  const float4 *whp = wh_packed ? reinterpret_cast<const float4 *>(ws + neu_pack_off(2 * (int64_t)lat.n_lattices * lat.max_rows * (hid + 1))) : nullptr;
   float2 *bme = lds;
   uint32_t *stage_s = (uint32_t *)(bme + neu_rows_al(lat.max_rows));  // two tiles: kNeuStageWords each
   float *bh_s = (float *)(stage_s + 2 * kNeuStageWords);
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
     // ---- B: u = Wh . beta_hat for the states this tile wrote (real rows only)
     neu_phase_b(bh_s, hs, n_lead, wh, hid, ctl_s, lead_s, tid, wv, lane,
                 [&](int sid) { return (const float *)bh_row(sid); },
-                [&](int sid, int col, float v) { if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = v; });
+                [&](int sid, int col, float v) { if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = v; }, whp);
     const unsigned long long t_b = NEU_NOW();
     __threadfence_block();
     const unsigned long long t_f = NEU_NOW();
@@ -588,11 +608,12 @@ template <int HC>
 __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
     nfst_batch lat, const float *__restrict__ label_x, const float *__restrict__ whT, const float *__restrict__ wvec, int hid,
     const float *__restrict__ beta_hat, const float *__restrict__ ws_fwd, const float *__restrict__ g_logbeta,
-    const float *__restrict__ g_betahat, float *gamma, float *grad_label_x, float *grad_w, float *ws) {
+    const float *__restrict__ g_betahat, float *gamma, float *grad_label_x, float *grad_w, float *ws, int wh_packed) {
   extern __shared__ float2 lds[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
+  const float4 *whp = wh_packed ? reinterpret_cast<const float4 *>(ws + neu_pack_off(2 * (int64_t)lat.n_lattices * lat.max_rows * hid)) : nullptr;
   float2 *bme = lds;
   float *lam = (float *)(bme + neu_rows_al(lat.max_rows));
   uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
@@ -771,7 +792,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
                 [&](int sid, int col, float v) {
                   if (sid < m.n_rows)
                     eta_w[(size_t)sid * hid + col] = v + (g_betahat ? g_betahat[((size_t)m.row_off + sid) * hid + col] : 0.0f);
-                });
+                }, whp);
     __threadfence_block();
     __syncthreads();
   }
