@@ -1,6 +1,7 @@
-"""Randomised check of the posterior sampler: random batches (sizes, widths, degrees up to 60 arcs per state, table
+"""(Test infrastructure: uses the oracle, hence under tests/; a script, not collected by pytest.)
+Randomised check of the posterior sampler: random batches (sizes, widths, degrees up to 60 arcs per state, table
 weights, caller scores, K), the three ways k_sample reads a lattice against each other, and every walk checked as an
-accepting path with log q = score - log Z.  python profiles/tune/fuzz_sampling.py [n_batches] [seed]"""
+accepting path with log q = score - log Z.  python tests/fuzz/fuzz_sampling.py [n_batches] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -1,6 +1,7 @@
-"""Randomised check of the tile-wave kernels (forward-backward, beta only, Viterbi) against the oracle and against the
+"""(Test infrastructure: uses the oracle, hence under tests/; a script, not collected by pytest.)
+Randomised check of the tile-wave kernels (forward-backward, beta only, Viterbi) against the oracle and against the
 loader / decoder / sweep pipeline (NFST_TW=0): random batch sizes, lattice sizes, widths, spans, degrees, table weights,
-caller scores.  python profiles/tune/fuzz_tile_waves.py [n_batches] [seed]"""
+caller scores.  python tests/fuzz/fuzz_tile_waves.py [n_batches] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
