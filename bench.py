@@ -19,10 +19,19 @@ batch size is timed as well and reported under ``config.aux`` ("per_gpu_256" /
 processes (fresh children, before this process touches the GPU); under
 ``torch.distributed.run`` it is one of the ranks.
 
+The timed loop ROTATES over several distinct resident batches (four at 256 lattices per GPU): one
+batch moves ~131 MB per launch, less than the 256 MiB Infinity Cache, so replaying a single batch
+would measure the die-level cache, not HBM (MI355X_MICROARCH.md: a line stays resident only while
+everything touched between two of its uses fits in ~256 MiB).  With the rotation ~390 MB of other
+lattices and outputs pass between two uses of a line: every launch starts cold.  The replayed figure
+is reported beside it (``roofline.kernel_ms_replay``); ``value``, ``roofline.frac`` and the rocprofv3
+summaries of the same command are the cold ones.
+
 Rank 0 prints one JSON line: value = lattice arcs processed by all ranks per
 second; ``roofline`` = algorithmic HBM bytes (32 B/arc +
 24 B/state) per launch / average kernel duration from HIP events, against the
-8 TB/s HBM3E peak; ``cpu_baseline`` = the CPU oracle's float64 forward-backward
+8 TB/s HBM3E peak (``frac``), and beside it ``frac_hw`` = the HBM bytes the PMC counters saw per
+launch (profiles/<tag>_pmc_traffic.json, taken on this same command) / the same duration / peak; ``cpu_baseline`` = the CPU oracle's float64 forward-backward
 (oracle/nfst_oracle.c, OpenMP over lattices) on the same batch on this box's
 host cores, rank 0 at N=1 only.  ``config.aux`` (N = 1): timed lines for the other
 BASELINE configs -- [2] 64 SNIPS-shaped lattices, [4] sampling K=16 + Viterbi with
@@ -78,21 +87,29 @@ def self_launch(n: int) -> int:
 
 
 # ----------------------------------------------------------------------------- helpers
-def pmc_traffic_bytes():
+TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first; each names its workload
+
+
+def pmc_traffic_bytes(lattices_per_gpu: int, rotate: int):
     """HBM bytes per k_forward_backward launch from the committed rocprofv3 PMC passes
     (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in separate runs of this benchmark, KiB per
     dispatch).  gfx950 correction from MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 64 B per
-    128-B request of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        return (2.0 * d["FETCH_SIZE"]["mean_per_dispatch_KiB"] + d["WRITE_SIZE"]["mean_per_dispatch_KiB"]) * 1024.0, \
-            os.path.basename(files[-1])
-    except Exception:
-        return None, None
+    128-B request of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact.
+    The file is chosen by name, newest round first, and must have been taken on this workload (the
+    number of lattices per GPU it records; files of round 2 carry none and were taken at 256, replaying
+    one batch).  Returns (bytes, file name, "rotating" | "replay")."""
+    for name in TRAFFIC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if int(d.get("lattices_per_gpu", 256)) != lattices_per_gpu:
+            continue
+        mode = "rotating" if int(d.get("rotate", 1)) > 1 else "replay"
+        if (rotate > 1) != (mode == "rotating"):
+            continue
+        return (2.0 * d["FETCH_SIZE"]["mean_per_dispatch_KiB"] + d["WRITE_SIZE"]["mean_per_dispatch_KiB"]) * 1024.0, name, mode
+    return None, None, None
 
 
 def host_cores() -> int:
@@ -251,6 +268,30 @@ class Stepper:
             self.pending.popleft().wait()
 
 
+class Rotor:
+    """Round-robin over steppers of distinct resident batches (see the module docstring: cold launches)."""
+
+    def __init__(self, steppers):
+        self.steppers, self.i = list(steppers), 0
+        self.cur = self.steppers[0]
+
+    def launch(self):
+        self.cur = self.steppers[self.i % len(self.steppers)]
+        self.i += 1
+        return self.cur.launch()
+
+    def reduce_loss(self, r):
+        return self.cur.reduce_loss(r)
+
+    def drain(self):
+        for s in self.steppers:
+            s.drain()
+
+    def arcs_of_steps(self, first: int, n: int) -> int:
+        """lattice arcs of steps first .. first + n - 1 of the rotation"""
+        return sum(int(self.steppers[(first + k) % len(self.steppers)].lat.n_dp_arcs.sum()) for k in range(n))
+
+
 def timed_region(stepper, steps, warmup, world, dev, event_every=8, launch=None):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize on
     both sides.  Returns (wall seconds -- max over ranks --, list of per-launch kernel ms, one per
@@ -268,7 +309,7 @@ def timed_region(stepper, steps, warmup, world, dev, event_every=8, launch=None)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    span = max(1, min(event_every, steps))
+    span = max(1, min(event_every if steps >= 32 else 4, steps))  # (a 20-step run still gives five windows)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps // span)]
     t0 = time.perf_counter()
     for i in range(steps):
@@ -309,10 +350,10 @@ def window_stats(windows):
     return {"n_windows": int(w.size), "min_ms": float(w.min()), "median_ms": float(np.median(w)), "max_ms": float(w.max())}
 
 
-def build_batch(B, rank, width, dev, **pack):
+def build_batch(B, rank, width, dev, first_seed=None, **pack):
     from nfst_amd import synth
     from nfst_amd.lattice import LatticeBatch
-    lats = synth.bench_batch(B, first_seed=1234 + rank * B, width=width)
+    lats = synth.bench_batch(B, first_seed=(1234 + rank * B) if first_seed is None else first_seed, width=width)
     t0 = time.perf_counter()
     lat = LatticeBatch.from_synth(lats, **pack)
     pack_s = time.perf_counter() - t0
@@ -355,6 +396,13 @@ def aux_single_gpu(dev, theta256, steps):
     lat = LatticeBatch.from_synth(lats, device=dev)
     aux["configs2_snips_shaped_b64"] = fb_line(lat, th)
     aux["configs2_snips_shaped_b64"]["viterbi_ms"] = time_op(lambda: ops.viterbi(lat, th), iters)
+    # batch size 1: the reference's decoder scores one lattice at a time (src/decode/decoder.py:77-79)
+    one = LatticeBatch.from_synth(lats[:1], device=dev)
+    aux["decode_b1_snips_shaped"] = dict(fb_line(one, th), viterbi_ms=time_op(lambda: ops.viterbi(one, th), iters))
+    lats1 = synth.bench_batch(1, first_seed=1234)
+    one = LatticeBatch.from_synth(lats1, device=dev)
+    aux["decode_b1_configs1_lattice"] = dict(fb_line(one, theta256), viterbi_ms=time_op(lambda: ops.viterbi(one, theta256), iters))
+    del one
     # configs[4]: posterior sampling K = 16 + Viterbi on transliteration-shaped (edit) lattices,
     # float32 scores vs the same scores rounded to bfloat16 (float32 accumulation either way)
     rng = np.random.default_rng(4)
@@ -397,7 +445,10 @@ def main():
     ap.add_argument("--width", type=int, default=16, help="layer width of the synthetic lattices")
     ap.add_argument("--graph", action="store_true", help="replay a HIP graph of the step instead of launching from Python "
                     "(measured slower on ROCm 7.2: 67.8 vs 59.2 us per step)")
-    ap.add_argument("--event-every", type=int, default=8, help="HIP events around runs of n back-to-back launches")
+    ap.add_argument("--event-every", type=int, default=8, help="HIP events around runs of n back-to-back launches (4 when steps < 32)")
+    ap.add_argument("--rotate", type=int, default=0,
+                    help="distinct resident batches the timed loop rotates over (0 = as many as it takes to push more than "
+                         "the 256 MiB Infinity Cache between two uses of a line: 4 at 256 lattices per GPU, 1 from 1024 on)")
     ap.add_argument("--torch-sum", action="store_true", help="reduce the loss with torch.sum instead of the kernel's fused total")
     ap.add_argument("--mode", default="fb", choices=["fb", "fb_sweeps_only", "bwd"],
                     help="fb = the benchmark; the others are diagnostics (not the BASELINE metric)")
@@ -455,6 +506,17 @@ def main():
     fused = args.mode != "bwd" and not args.torch_sum and not args.graph  # a captured launch has one fixed slot
     asc = torch.randn(lat.total_arcs, device=dev) * 0.1 if args.arc_scores else None
     st = Stepper(lat, theta, dev, world, mode=args.mode, fused=fused, arc_scores=asc)
+    # cold launches: rotate over distinct resident batches (module docstring).  One launch touches ~0.51 MB per
+    # lattice (tile programs, canonical arcs, outputs); between two uses of a line the other batches of the rotation
+    # must move more than the Infinity Cache holds.
+    touched = 0.51e6 * B
+    n_rot = args.rotate if args.rotate > 0 else (1 if (touched > 300e6 or args.graph) else int(min(8, 1 + -(-300e6 // touched))))
+    steppers = [st]
+    for r in range(1, n_rot):
+        _, lat_r, _ = build_batch(B, rank, args.width, dev, first_seed=1234 + (world * r + rank) * B + 100000 * r, **pack)
+        asc_r = torch.randn(lat_r.total_arcs, device=dev) * 0.1 if args.arc_scores else None
+        steppers.append(Stepper(lat_r, theta, dev, world, mode=args.mode, fused=fused, arc_scores=asc_r))
+    rotor = Rotor(steppers)
 
     # --graph: a step is launched by replaying a HIP graph of the forward-backward kernel (the
     # engine allocates nothing, so one warm-up call makes it capturable); the reduction of the loss
@@ -478,9 +540,18 @@ def main():
             graph.replay()
             return st.out
 
-    dt, windows, loss = timed_region(st, args.steps, args.warmup, world, dev, args.event_every, launch)
-    total_arcs = sum_over_ranks(arcs, world, dev)
+    dt, windows, loss = timed_region(rotor, args.steps, args.warmup, world, dev, args.event_every, launch)
+    arcs_timed = rotor.arcs_of_steps(args.warmup, args.steps) if launch is None else arcs * args.steps
+    total_arcs_timed = sum_over_ranks(arcs_timed, world, dev)
     kern_ms = float(np.mean(windows))
+    alg_bytes = float(np.mean([s_.lat.algorithmic_bytes("forward_backward") for s_ in steppers]))
+    # the same step replaying ONE resident batch (what rounds 1-2 reported): its ~131 MB per launch fit the Infinity Cache
+    replay_ms = None
+    if n_rot > 1:
+        _, win_r, _ = timed_region(st, max(8, min(args.steps, 64)), 4, world, dev, args.event_every)
+        replay_ms = float(np.mean(win_r))
+    replay_frac = None if replay_ms is None else lat.algorithmic_bytes() / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    del rotor, steppers[1:]
 
     # the other per-GPU batch size of the BASELINE configs, every rank, same protocol, fewer steps
     aux = {}
@@ -509,11 +580,11 @@ def main():
 
     if rank == 0:
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        tbytes, tsrc = pmc_traffic_bytes() if (args.mode == "fb" and B == 256 and args.width == 16) else (None, None)
+        tbytes, tsrc, tmode = pmc_traffic_bytes(B, n_rot) if (args.mode == "fb" and args.width == 16 and not args.arc_scores) else (None, None, None)
         shape = "BASELINE configs[1]" if B == 256 else ("BASELINE configs[3] (8192 lattices over 8 GPUs)" if B == 1024 else "custom")
         out = {
             "metric": "lattice-arcs/sec forward-backward (log-Z)",
-            "value": total_arcs * args.steps / dt,
+            "value": total_arcs_timed / dt,
             "unit": "lattice-arcs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -527,6 +598,10 @@ def main():
             "config": {"workload": f"{shape}: {B} synthetic lattices per GPU, ~2k states / ~20k arcs "
                                    f"(layer width {args.width}), alpha+beta+logZ+arc posteriors",
                        "lattices_per_gpu": B, "lattices_total": B * world, "arcs_per_gpu": arcs, "vocab": 256,
+                       "resident_batches_rotated": n_rot,
+                       "cache_state": ("cold: %d distinct resident batches take turns, ~%.0f MB touched between two uses of a line "
+                                       "(Infinity Cache: 256 MiB)" % (n_rot, (n_rot - 1) * touched / 1e6)) if n_rot > 1 else
+                                      ("one resident batch, ~%.0f MB touched per launch" % (touched / 1e6)),
                        "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()),
                        "host_pack_s": pack_s,
                        "launch": "hip_graph_replay" if args.graph else "python",
@@ -535,10 +610,15 @@ def main():
                        "aux": aux},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "frac_is": "algorithmic bytes (SURVEY 8d: 32 B/arc + 24 B/state) / kernel_ms_cold / peak",
+                         # bytes the memory system really moved per launch (PMC counters), on the same duration
                          "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,
-                         "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
-                         "hw_utilisation_from_traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernel": "k_forward_backward", "kernel_ms": kern_ms, "kernel_ms_windows": window_stats(windows),
+                         "frac_hw": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc, "traffic_taken_on": tmode,
+                         "kernel": "k_forward_backward", "kernel_ms": kern_ms,
+                         "kernel_ms_cold": kern_ms if n_rot > 1 else None, "kernel_ms_replay": replay_ms if n_rot > 1 else kern_ms,
+                         "frac_replay": replay_frac,
+                         "kernel_ms_windows": window_stats(windows),
                          "algorithmic_bytes": alg_bytes},
         }
         out["roofline"]["hbm_copy_measured"] = measured_copy_gbs(dev)

@@ -11,9 +11,12 @@ import os
 import torch  # noqa: F401  -- first, so that torch's bundled HIP runtime is the one the process uses
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NFST_LIB: an experimental build of the same sources (python -m nfst_amd.build --variant TAG -D...),
-# for A/B measurements inside one GPU box call; the product library otherwise
-LIB_PATH = os.environ.get("NFST_LIB") or os.path.join(_HERE, "lib", "libnfst_hip.so")
+# The product library.  Only a tuning session (NFST_TUNING=1 in the environment) may put an experimental build of
+# the same sources in its place through NFST_LIB (python -m nfst_amd.build --variant TAG -D...: A/B measurements
+# inside one GPU box call); without NFST_TUNING the variable is ignored.
+LIB_PATH = os.path.join(_HERE, "lib", "libnfst_hip.so")
+if os.environ.get("NFST_TUNING") == "1" and os.environ.get("NFST_LIB"):
+    LIB_PATH = os.environ["NFST_LIB"]
 
 META_WORDS = 16
 (META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_TILES, META_BWD_OFF,
@@ -75,6 +78,7 @@ def _load():
         "nfst_strerror": (C.c_char_p, [C.c_int]),
         "nfst_abi_version": (C.c_int, []),
         "nfst_device_available": (C.c_int, []),
+        "nfst_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
         "nfst_pack_dense": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
         "nfst_pack_arcs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
         "nfst_packed_view": (C.c_int, [vp, BP]),
@@ -124,3 +128,25 @@ if lib.nfst_abi_version() != ABI_VERSION:
 def check(code: int, where: str, lattice: int = -1) -> None:
     if code != OK:
         raise NfstError(code, where, lattice)
+
+
+class tuning:
+    """``with tuning(tw=0, precise=0): ...`` -- launcher switches for tests and A/B measurements
+    (``nfst_tuning_set``, include/nfst_hip.h); the defaults come back on exit."""
+    DEFAULTS = dict(tw=1, fused=1, xcache=1, precise=-1, neu_pack=1, neu_small=1)
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(self.DEFAULTS)
+        if unknown:
+            raise ValueError(f"unknown tuning switches {sorted(unknown)}")
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            check(lib.nfst_tuning_set(k.encode(), int(v)), "nfst_tuning_set")
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            check(lib.nfst_tuning_set(k.encode(), int(self.DEFAULTS[k])), "nfst_tuning_set")
+        return False

@@ -9,6 +9,12 @@ struct LdsPlan {
   int rows2, v2, v4;
   __host__ __device__ LdsPlan(int max_rows, int vocab)
       : rows2((max_rows + 1) & ~1), v2((vocab + 3) & ~1), v4((vocab + 3) & ~3) {}
+  // the precise flavour (tile waves only: no staging rings): 16-byte values and label weights, ring slots of
+  // kSlotWordsP words, 16 bytes of trash per lane and sweep
+  __host__ __device__ int64_t fb_fixed_precise() const {
+    return ((int64_t)2 * rows2 + v2) * 16 + (int64_t)v4 * 4 + 2 * kSweepFlags * 4 + 2048;
+  }
+  __host__ __device__ int64_t bwd_fixed_precise() const { return ((int64_t)rows2 + v2) * 16 + kSweepFlags * 4 + 1024; }
   // words of one sweep's rings
   static __host__ __device__ int64_t sweep_words(int R, int RS, bool extra) {
     (void)extra;
@@ -32,21 +38,25 @@ struct LdsPlan {
 // for the decoder; with per-arc extras the last four (two) waves are the extras waves; every wave
 // helps with the initialisation and the outputs.
 // TW (512 threads, all-compact batches): wave 0 sweeps (tile_sweep2), waves 1, 2, 3, 5 are its tile waves.
-template <int NT, int EXTRA, bool TW = false>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both
+template <int NT, int EXTRA, bool TW = false, bool PREC = false>  // EXTRA: 0 none, 1 table weights or caller scores, 2 both
 __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc, int R, int RS, float *logbeta,
                                                  double *logz64, float *logz32, float2 *beta_me) {
-  extern __shared__ float2 lds[];
+  static_assert(!PREC || TW, "precise flavour: tile waves");
+  typedef typename ValOf<PREC>::T VT;
+  extern __shared__ float2 lds_raw[];
+  VT *lds = reinterpret_cast<VT *>(lds_raw);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   // this thread's label score: requested before anything waits for the meta record
   const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
-  float2 *beta = lds;
-  float2 *th = lds + plan.rows2;
+  VT *beta = lds;
+  VT *th = lds + plan.rows2;
   uint32_t *ring = (uint32_t *)(th + plan.v2);
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t *raw = ring + (size_t)R * kSlotWords;
+  constexpr int kTwSlot = PREC ? kSlotWordsP : kSlotWords2;
   // NT = 512: the workgroup has the CU to itself: wave 2 loads for the decoder (deep staging
   // ring); NT = 256: two workgroups per CU, the decoder loads for itself
   // slot -> canonical arc map of the backward program (only read by the kernels with EXTRA)
@@ -64,32 +74,33 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   // weight / tile waves: the records and maps of their first tiles go in flight now, the first gathers before the barrier
   const bool x_wave = TW ? (wv == 1 || wv == 2 || wv == 3 || wv == 5) : (EXTRA != 0 && wv >= kFirstX);
   const int x_index = TW ? (wv < 4 ? wv - 1 : 3) : wv - kFirstX;
-  WeightWave<8, kNE, EXTRA, TW> xw8;
+  WeightWave<8, kNE, EXTRA, TW, PREC> xw8;
   if (x_wave && m.bwd_u == 8) xw8.start_maps(lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, x_index, lane);
-  for (int i = tid; i < m.n_rows; i += NT) beta[i] = make_float2(0.0f, __int_as_float(kEZero));
+  for (int i = tid; i < m.n_rows; i += NT) val_set(beta[i], 0.0f, kEZero);
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
   if (x_wave && m.bwd_u == 8) xw8.start_gathers(lane);
   __syncthreads();
-  int *flags = (int *)(ring + (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA)));
+  int *flags = (int *)(ring + (TW ? (int64_t)R * kTwSlot : LdsPlan::sweep_words(R, RS, EXTRA)));
   if (tid == 0) {
-    beta[m.sink] = make_float2(0.5f, __int_as_float(1));
+    val_set(beta[m.sink], 0.5f, 1);
     for (int i = 0; i < kSweepFlags; ++i) flags[i] = 0;
   }
   __syncthreads();
   const bool tw_v2 = TW && m.bwd_wide == 0;
   if (x_wave) {
-    run_weights<kNE, EXTRA, TW>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, x_index, ring, R, flags, th, beta,
-                                tw_v2, lds_addr(flags + kSweepFlags) + lane * 8, 0u, 0, lane);
+    run_weights<kNE, EXTRA, TW, PREC>(xw8, m.bwd_u, lat.bwd_stream + m.bwd_off, bwd_perm, m.bwd_tiles, ex, x_index, ring, R, flags,
+                                      (const float2 *)th, (const float2 *)beta, tw_v2, lds_addr(flags + kSweepFlags) + lane * (PREC ? 16 : 8), 0u, 0, lane);
   } else if constexpr (TW) {
     if (wv == 0) {
       __builtin_amdgcn_s_setprio(3);
-      if (tw_v2) tile_sweep2<4, kNE>(m.bwd_tiles, ring, R, flags, flags + 4, lane);
+      if constexpr (PREC) tile_sweep2p<kNE>(m.bwd_tiles, ring, R, flags, flags + 4, lane);
+      else if (tw_v2) tile_sweep2<4, kNE>(m.bwd_tiles, ring, R, flags, flags + 4, lane);
       else tile_sweep<4, true, kNE>(m.bwd_tiles, ring, R, flags, flags + 4, lane);
       __builtin_amdgcn_s_setprio(0);
     }
   } else if (wv < (kSelf ? 2 : 3))
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv, m.bwd_u, m.bwd_wide != 0, raw, RS, lat.bwd_stream + m.bwd_off,
-              m.bwd_tiles, ring, R, flags, beta, th, lane);
+              m.bwd_tiles, ring, R, flags, (float2 *)beta, (const float2 *)th, lane);
   __syncthreads();
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   }
   for (int i = tid; i < m.n_rows; i += NT) {
     if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
-    if (beta_me) beta_me[m.row_off + i] = beta[i];
+    if (beta_me) beta_me[m.row_off + i] = me_f2(beta[i]);
   }
 }
 
@@ -136,21 +147,25 @@ __device__ __forceinline__ float arc_posterior(const float2 av, const float2 bv,
 // TW (1024 threads): tile waves -- no loader, no staging ring, no decoder: the eight waves 2, 3, 6, 7, 10, 11, 14, 15
 // (the SIMDs the sweep waves are not on) decode every fourth tile of their sweep's program straight from
 // HBM into the decoded ring, label weights and per-arc extras included (WeightWave<.., FULL>).
-template <int NT, int EXTRA, bool FUSED = false, bool TW = false>
+template <int NT, int EXTRA, bool FUSED = false, bool TW = false, bool PREC = false>
 __global__ __launch_bounds__(NT) void k_forward_backward(
     nfst_batch lat, nfst_scores sc, int R, int RS, float *__restrict__ logalpha, float *__restrict__ logbeta,
     double *__restrict__ logz64, float *__restrict__ logz32, double *__restrict__ logz_total, int total_slot,
     float *__restrict__ posterior,
     float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
-  extern __shared__ float2 lds[];
+  static_assert(!PREC || (TW && EXTRA != 3), "precise flavour: tile waves, per-arc extras from HBM / L2");
+  typedef typename ValOf<PREC>::T VT;
+  extern __shared__ float2 lds_raw[];
+  VT *lds = reinterpret_cast<VT *>(lds_raw);
+  constexpr int kTwSlot = PREC ? kSlotWordsP : kSlotWords2;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   // this thread's label score: requested before anything waits for the meta record
   const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;
   const Meta m = load_meta(lat.meta, b);
   const LdsPlan plan(lat.max_rows, lat.vocab);
-  float2 *alpha = lds;
-  float2 *beta = lds + plan.rows2;
-  float2 *th = lds + 2 * plan.rows2;
+  VT *alpha = lds;
+  VT *beta = lds + plan.rows2;
+  VT *th = lds + 2 * plan.rows2;
   float *gth = (float *)(th + plan.v2);  // [V] label histogram (only if grad_theta)
   uint32_t *ring = (uint32_t *)(gth + plan.v4);
   const Extra ex{lat.weighted ? lat.arc_w : nullptr, sc.arc_scores};
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   const int my_tiles = bwd_side ? m.bwd_tiles : m.fwd_tiles;
   const int my_u = bwd_side ? m.bwd_u : m.fwd_u;
   const bool my_wide = (bwd_side ? m.bwd_wide : m.fwd_wide) != 0;
-  uint32_t *my_ring = bwd_side ? ring : ring + (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA));
+  uint32_t *my_ring = bwd_side ? ring : ring + (TW ? (int64_t)R * kTwSlot : LdsPlan::sweep_words(R, RS, EXTRA));
   const bool tw_v2 = TW && !my_wide;  // (the decoded-tile format of tile_sweep2: programs with narrow groups)
   uint32_t *my_raw = my_ring + (size_t)R * kSlotWords;
   // NT = 1024: the workgroup has the CU to itself: waves 4 / 5 load for the decoders (deep
@@ -205,18 +220,19 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     loader_start(my_u, my_prog, my_tiles, my_raw, RS, lane);
   }
   // extras waves: the slot -> arc maps of their first tiles go in flight now, the first gathers before the barrier
-  WeightWave<8, kNE, EXTRA, TW> xw8;
+  WeightWave<8, kNE, EXTRA, TW, PREC> xw8;
   if (x_wave && my_u == 8) xw8.start_maps(my_prog, my_perm, my_tiles, ex, x_index, lane);
   for (int i = tid; i < m.n_rows; i += NT) {
-    alpha[i] = make_float2(0.0f, __int_as_float(kEZero));
-    beta[i] = make_float2(0.0f, __int_as_float(kEZero));
+    val_set(alpha[i], 0.0f, kEZero);
+    val_set(beta[i], 0.0f, kEZero);
   }
   load_theta(th, sc.theta, sc.theta_stride, b, lat.vocab, tid, NT, theta_first);
   if (grad_theta) for (int l = tid; l < lat.vocab; l += NT) gth[l] = 0.0f;
   if (x_wave && my_u == 8) xw8.start_gathers(lane);
   __syncthreads();
-  int *flags = (int *)(ring + 2 * (TW ? (int64_t)R * kSlotWords2 : LdsPlan::sweep_words(R, RS, EXTRA)));
+  int *flags = (int *)(ring + 2 * (TW ? (int64_t)R * kTwSlot : LdsPlan::sweep_words(R, RS, EXTRA)));
   float *xc = (float *)(flags + 2 * kSweepFlags + 256);  // (behind the flags and the 1 KiB of trash)
+  constexpr int kTrash = PREC ? 16 : 8;  // bytes of trash per lane and sweep (the non-leader lanes' stores)
   const int xc_first = m.arc_off & ~3;
   if (kCached) {
     // 16 bytes at a time over the aligned interior, scalar at the ends (nothing is read outside the lattice's arcs)
@@ -239,8 +255,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     }
   }
   if (tid == 0) {
-    beta[m.sink] = make_float2(0.5f, __int_as_float(1));
-    alpha[0] = make_float2(0.5f, __int_as_float(1));
+    val_set(beta[m.sink], 0.5f, 1);
+    val_set(alpha[0], 0.5f, 1);
     for (int i = 0; i < 2 * kSweepFlags; ++i) flags[i] = 0;
   }
   __syncthreads();
@@ -301,31 +317,32 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   if constexpr (FUSED) {
     if (wv < 2) {
       const uint32_t trash = lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 512) + lane * 8;
-      if (my_wide) FusedSweep<true>::run(my_prog, my_tiles, bwd_side ? beta : alpha, th, trash, lane);
-      else FusedSweep<false>::run(my_prog, my_tiles, bwd_side ? beta : alpha, th, trash, lane);
+      if (my_wide) FusedSweep<true>::run(my_prog, my_tiles, (const float2 *)(bwd_side ? beta : alpha), (const float2 *)th, trash, lane);
+      else FusedSweep<false>::run(my_prog, my_tiles, (const float2 *)(bwd_side ? beta : alpha), (const float2 *)th, trash, lane);
     }
   } else if (x_wave) {
-    run_weights<kNE, EXTRA, TW>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags, th,
-                                bwd_side ? beta : alpha, tw_v2, lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 512) + lane * 8,
-                                lds_addr(xc), xc_first, lane);
+    run_weights<kNE, EXTRA, TW, PREC>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags,
+                                      (const float2 *)th, (const float2 *)(bwd_side ? beta : alpha), tw_v2,
+                                      lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 64 * kTrash) + lane * kTrash, lds_addr(xc), xc_first, lane);
   } else if constexpr (TW) {
     if (wv < 2) {
       int *fl = bwd_side ? flags : flags + kSweepFlags;
       __builtin_amdgcn_s_setprio(3);  // (the chain: 45.8 -> 44.3 us at 256 lattices)
       // (every program is compact: four slots per lane)
-      if (tw_v2) tile_sweep2<4, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
+      if constexpr (PREC) tile_sweep2p<kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
+      else if (tw_v2) tile_sweep2<4, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
       else tile_sweep<4, true, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
       __builtin_amdgcn_s_setprio(0);
     }
   } else if (wv < 4 || (!kSelf && (wv == 6 || wv == 7))) {
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog,
-                     my_tiles, my_ring, R, bwd_side ? flags : flags + kSweepFlags, bwd_side ? beta : alpha, th, lane);
+                     my_tiles, my_ring, R, bwd_side ? flags : flags + kSweepFlags, (float2 *)(bwd_side ? beta : alpha), (const float2 *)th, lane);
   }
   if (kPre > 0 && want_post && tid >= kSweepThreads) preload_arcs();
   __syncthreads();
-  const float2 zme = beta[0];
+  const float2 zme = me_f2(beta[0]);
   if (tid == 0) {
-    const double z = me_log64(zme);
+    const double z = me_log64(beta[0]);
     if (logz64) logz64[b] = z;
     if (logz_total) {
       atomicAdd(&logz_total[total_slot], z);
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int s0 = (int)(sdv[q] & 0xffffu), d0 = (int)(sdv[q] >> 16);
-      pp[q] = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[ll[q]], rz, ez, has_extra, xmv[q], xev[q]) : 0.0f;
+      pp[q] = (s0 != d0) ? arc_posterior(me_f2(alpha[s0]), me_f2(beta[d0]), me_f2(th[ll[q]]), rz, ez, has_extra, xmv[q], xev[q]) : 0.0f;
       if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
     }
     if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   for (int i = tid; i < m.n_rows; i += NT) {
     if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
     if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
-    if (beta_me) beta_me[m.row_off + i] = beta[i];
+    if (beta_me) beta_me[m.row_off + i] = me_f2(beta[i]);
   }
   if (want_post) {
     // the arc groups that were not preloaded: kPB groups per iteration, all loads issued
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       float hm = 1.0f;
       int he = 0;
       if (has_extra) exp_me_fast(kCached ? xc[a - xc_first] : ex.at(a), hm, he);
-      const float p = (s0 != d0) ? arc_posterior(alpha[s0], beta[d0], th[l0], rz, ez, has_extra, hm, he) : 0.0f;
+      const float p = (s0 != d0) ? arc_posterior(me_f2(alpha[s0]), me_f2(beta[d0]), me_f2(th[l0]), rz, ez, has_extra, hm, he) : 0.0f;
       if (posterior) posterior[a] = p;
       if (grad_theta && p > 0.0f) atomicAdd(&gth[l0], p);
     }

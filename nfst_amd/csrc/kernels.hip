@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -90,6 +91,47 @@ int cu_count() {
   return per_dev[dev];
 }
 
+// Switches of the launchers.  The environment is read ONCE, when the first launcher runs (never on the launch path
+// afterwards); nfst_tuning_set() changes a switch from the host side (tests and A/B measurements flip flavours inside
+// one process).  Every switch only selects among kernels that compute the same function.
+struct Tuning {
+  int64_t lds_reserve = 0;  // NFST_LDS_RESERVE_KB: LDS the one-lattice-per-CU flavours leave free on every CU
+  int tw = 1;               // NFST_TW=0: loader + decoder + sweep instead of tile waves
+  int fused = 1;            // NFST_NO_FUSED=1: never the fused sweeps
+  int xcache = 1;           // NFST_XCACHE=0: per-arc extras gathered from HBM / L2, never staged in LDS
+  int precise = -1;         // NFST_PRECISE: 0 never, 1 whenever it fits, unset: programs deeper than kPreciseTiles tiles
+  int neu_pack = 1;         // NFST_NEU_PACK=0: phase B reads Wh from the matrix itself
+  int neu_small = 1;        // NFST_NEU_NO_SMALL=1: two-phase neural kernels for every hidden size
+};
+Tuning &tuning() {
+  static Tuning t = [] {
+    Tuning r;
+    auto num = [](const char *name, long dflt) { const char *e = getenv(name); return e && *e ? strtol(e, nullptr, 10) : dflt; };
+    const long kb = num("NFST_LDS_RESERVE_KB", 0);
+    r.lds_reserve = (kb > 0 && kb <= 96) ? kb * 1024 : 0;
+    r.tw = num("NFST_TW", 1) != 0;
+    r.fused = num("NFST_NO_FUSED", 0) != 1;
+    r.xcache = num("NFST_XCACHE", 1) != 0;
+    r.precise = (int)num("NFST_PRECISE", -1);
+    r.neu_pack = num("NFST_NEU_PACK", 1) != 0;
+    r.neu_small = getenv("NFST_NEU_NO_SMALL") ? 0 : 1;
+    return r;
+  }();
+  return t;
+}
+int64_t lds_reserve() { return tuning().lds_reserve; }
+
+// the precise flavour (float64 mantissas, semiring.h) runs all-compact batches whose deepest program has more than
+// kPreciseTiles tiles, when at least four ring slots per sweep fit beside the 16-byte values
+int precise_ring(const nfst_batch *lat, int64_t fixed, int n_rings) {
+  const Tuning &tu = tuning();
+  if (!(lat->reserved0 & NFST_BATCH_ALL_COMPACT) || tu.precise == 0) return 0;
+  if (tu.precise != 1 && lat->max_tiles <= kPreciseTiles) return 0;
+  const int64_t r = (kMaxLds - lds_reserve() - fixed) / ((int64_t)kSlotWordsP * 4 * n_rings);
+  const int R = (int)(r > kMaxRing ? kMaxRing : r) & ~3;
+  return R >= 4 ? R : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -98,6 +140,21 @@ int nfst_device_available(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n > 0 ? 1 : 0;
+}
+
+int nfst_tuning_set(const char *name, int value) {
+  if (!name) return NFST_ERR_ARG;
+  Tuning &t = tuning();
+  const std::string n(name);
+  if (n == "tw") t.tw = value != 0;
+  else if (n == "fused") t.fused = value != 0;
+  else if (n == "xcache") t.xcache = value != 0;
+  else if (n == "precise") t.precise = value < 0 ? -1 : (value != 0);
+  else if (n == "neu_pack") t.neu_pack = value != 0;
+  else if (n == "neu_small") t.neu_small = value != 0;
+  else if (n == "lds_reserve_kb") t.lds_reserve = (value > 0 && value <= 96) ? (int64_t)value * 1024 : 0;
+  else return NFST_ERR_ARG;
+  return NFST_OK;
 }
 
 int64_t nfst_lds_bytes(const nfst_batch *lat) {
@@ -113,16 +170,6 @@ int64_t nfst_lds_bytes(const nfst_batch *lat) {
 // NFST_LDS_RESERVE_KB (environment, read once): LDS the one-lattice-per-CU flavour leaves free on
 // every CU, so that a small kernel of another stream -- RCCL's all-reduce of the loss -- finds a CU
 // to run on beside a sweep workgroup instead of waiting for one to retire.  Costs ring depth only.
-static int64_t lds_reserve() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char *e = getenv("NFST_LDS_RESERVE_KB");
-    const long kb = e ? strtol(e, nullptr, 10) : 0;
-    v = (kb > 0 && kb <= 96) ? kb * 1024 : 0;
-  }
-  return v;
-}
-
 struct RingCfg { int R, RS; bool self; };
 static bool ring_config(const LdsPlan &plan, bool fb, bool extra, bool deep, RingCfg *c) {
   const int n_rings = fb ? 2 : 1;
@@ -152,9 +199,21 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   RingCfg cfg;
   if (!ring_config(plan, false, extra, lat->n_lattices <= cu_count(), &cfg)) return NFST_ERR_LIMIT;
   if (extra && ((uintptr_t)lat->bwd_perm & 15)) return NFST_ERR_ARG;  // the extras waves read the slot -> arc map 16 bytes at a time
+  const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
+  if (const int Rp = precise_ring(lat, plan.bwd_fixed_precise(), 1)) {
+    const int64_t ldsp = plan.bwd_fixed_precise() + (int64_t)Rp * kSlotWordsP * 4;
+#define NFST_LAUNCH_BWD_P(EX)                                                                            \
+    {                                                                                                  \
+      if ((rc = set_lds(k_backward<512, EX, true, true>, ldsp))) return rc;                            \
+      hipLaunchKernelGGL((k_backward<512, EX, true, true>), dim3(lat->n_lattices), dim3(512), (size_t)ldsp, \
+                         (hipStream_t)stream, *lat, *scores, Rp, 0, logbeta, logz64, logz32, (float2 *)beta_me); \
+    }
+    if (both) NFST_LAUNCH_BWD_P(2) else if (extra) NFST_LAUNCH_BWD_P(1) else NFST_LAUNCH_BWD_P(0)
+#undef NFST_LAUNCH_BWD_P
+    return hip_status(hipGetLastError());
+  }
   // one lattice per CU, all-compact: tile waves (NFST_TW=0: loader + decoder + sweep, for A/B runs)
-  const char *tw_env = getenv("NFST_TW");
-  const bool tw = !cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && !(tw_env && tw_env[0] == '0');
+  const bool tw = !cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tuning().tw;
   const int64_t tw_fixed = plan.bwd_bytes(0, 0, extra) + 512;  // + 64 x 8 bytes of trash for the non-leader lanes' stores
   if (tw) {
     const int64_t r = (kMaxLds - lds_reserve() - tw_fixed) / ((int64_t)kSlotWords2 * 4);
@@ -176,7 +235,6 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
                        (hipStream_t)stream, *lat, *scores, R, RS, logbeta, logz64, logz32, (float2 *)beta_me); \
   }
   // 512 threads: loader + decoder + sweep (deep); 256 threads: self-loading decoder + sweep
-  const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
   if (tw) { if (both) NFST_LAUNCH_BWD_TW(2) else if (extra) NFST_LAUNCH_BWD_TW(1) else NFST_LAUNCH_BWD_TW(0) }
   else if (!cfg.self) { if (both) NFST_LAUNCH_BWD(512, 2) else if (extra) NFST_LAUNCH_BWD(512, 1) else NFST_LAUNCH_BWD(512, 0) }
   else { if (both) NFST_LAUNCH_BWD(256, 2) else if (extra) NFST_LAUNCH_BWD(256, 1) else NFST_LAUNCH_BWD(256, 0) }
@@ -199,18 +257,31 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   const LdsPlan plan(lat->max_rows, lat->vocab);
   const int cus = cu_count();
   RingCfg cfg;
+  if (extra && (((uintptr_t)lat->fwd_perm | (uintptr_t)lat->bwd_perm | (uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 15))
+    return NFST_ERR_ARG;  // (maps and extras are read 16 bytes at a time)
+  // deep programs: the precise flavour (tile waves with float64 mantissas), whatever the number of lattices
+  if (const int Rp = precise_ring(lat, plan.fb_fixed_precise(), 2)) {
+    const int64_t ldsp = plan.fb_fixed_precise() + (int64_t)Rp * kSlotWordsP * 4 * 2;
+#define NFST_LAUNCH_TWP(EX)                                                                               \
+    {                                                                                                   \
+      if ((rc = set_lds(k_forward_backward<1024, EX, false, true, true>, ldsp))) return rc;             \
+      hipLaunchKernelGGL((k_forward_backward<1024, EX, false, true, true>), dim3(lat->n_lattices), dim3(1024), (size_t)ldsp, \
+                         (hipStream_t)stream, *lat, *scores, Rp, 0, logalpha, logbeta, logz64, logz32, logz_total,        \
+                         (int)total_slot, posterior, grad_theta, (float2 *)beta_me);                    \
+    }
+    if (both) NFST_LAUNCH_TWP(2) else if (extra) NFST_LAUNCH_TWP(1) else NFST_LAUNCH_TWP(0)
+#undef NFST_LAUNCH_TWP
+    return hip_status(hipGetLastError());
+  }
   // every program compact and no per-arc extras: the fused sweeps (no rings at all)
-  const char *no_fused = getenv("NFST_NO_FUSED");  // (A/B measurements: "1" selects the loader / decoder / sweep pipeline)
   // Measured (profiles/r02_ab_fused.txt): 227 against 164 G arcs/s at 1024 lattices, 210 against 160 at 2048,
   // equal at 512; with one lattice per CU the three-wave pipeline is 10 % faster (46.8 against 51.8 us).
-  const bool fused = !extra && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && lat->n_lattices > cus &&
-                     !(no_fused && no_fused[0] == '1');
+  const bool fused = !extra && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && lat->n_lattices > cus && tuning().fused;
   // one lattice per CU: tile waves instead of loader + decoder (NFST_TW=0: the three-wave pipeline, for A/B runs)
-  const char *tw_env = getenv("NFST_TW");
   bool tw = false, cached = false;
   if (fused) cfg = {0, 0, lat->n_lattices > cus};
   else if (!ring_config(plan, true, extra, lat->n_lattices <= cus, &cfg)) return NFST_ERR_LIMIT;
-  else if (!cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && !(tw_env && tw_env[0] == '0')) {
+  else if (!cfg.self && (lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tuning().tw) {
     tw = true;  // no staging ring; ring slots of kSlotWords2 words
     const int64_t slot = (int64_t)kSlotWords2 * 4 * 2;
     const int64_t r = (kMaxLds - lds_reserve() - plan.fb_bytes(0, 0, extra)) / slot;
@@ -219,8 +290,7 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
     // per-arc extras staged in LDS (the sum of both arrays, 4 bytes per arc of the largest lattice) when a ring of at least
     // eight slots per sweep still fits beside them (lattices up to ~14k arcs at 2k states); RS carries the room in floats
     const int64_t max_arcs = ((int64_t)lat->reserved0 >> NFST_BATCH_MAX_ARCS_SHIFT) & NFST_BATCH_MAX_ARCS_CAP;
-    const char *xc_env = getenv("NFST_XCACHE");  // (NFST_XCACHE=0: gather from HBM / L2 instead, for A/B runs)
-    if (extra && max_arcs > 0 && max_arcs < NFST_BATCH_MAX_ARCS_CAP && !(xc_env && xc_env[0] == '0')) {
+    if (extra && max_arcs > 0 && max_arcs < NFST_BATCH_MAX_ARCS_CAP && tuning().xcache) {  // (NFST_XCACHE=0: gather from HBM / L2 instead, for A/B runs)
       const int64_t words = (max_arcs + 8 + 3) & ~(int64_t)3;
       const int64_t rc2 = ((kMaxLds - lds_reserve() - plan.fb_bytes(0, 0, extra) - words * 4) / slot) & ~(int64_t)3;
       if (rc2 >= 8) {  // (with four slots per sweep the tile waves cannot run ahead: 69 us against 50 from HBM / L2 at 256 x 20k arcs)
@@ -229,8 +299,6 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
       }
     }
   }
-  if (extra && (((uintptr_t)lat->fwd_perm | (uintptr_t)lat->bwd_perm | (uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 15))
-    return NFST_ERR_ARG;  // (maps and extras are read 16 bytes at a time)
   const int R = cfg.R, RS = cfg.RS;
   const int64_t lds = tw ? plan.fb_bytes(0, 0, extra) + (int64_t)R * kSlotWords2 * 4 * 2 + (cached ? (int64_t)RS * 4 : 0) : plan.fb_bytes(R, RS, extra);
 #define NFST_LAUNCH_FB(NT, EX)                                                                            \
@@ -285,13 +353,12 @@ int nfst_viterbi(const nfst_batch *lat, const nfst_scores *scores, float *best, 
   if ((rc = check_scores(lat, scores))) return rc;
   if (!best || !paths || !lengths || max_len <= 0) return NFST_ERR_ARG;
   // all-compact batches: the tile-wave kernel (NFST_TW=0: one wave reading the program from global memory, for A/B runs)
-  const char *tw_env = getenv("NFST_TW");
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
   const int64_t tw_fixed = VitLds(lat->max_rows, lat->vocab).fixed();
   int64_t tw_r = (kMaxLds - tw_fixed) / ((int64_t)kSlotWords2 * 4);
   tw_r = (tw_r > kMaxRing ? kMaxRing : tw_r) & ~(int64_t)3;
-  if ((lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tw_r >= 8 && !(tw_env && tw_env[0] == '0') &&  // (its trips check four tiles ahead: eight slots)
+  if ((lat->reserved0 & NFST_BATCH_ALL_COMPACT) && tw_r >= 8 && tuning().tw &&  // (its trips check four tiles ahead: eight slots)
       (!extra || (((uintptr_t)lat->arc_w | (uintptr_t)scores->arc_scores) & 3) == 0) && ((uintptr_t)lat->bwd_perm & 15) == 0) {
     const int64_t lds = tw_fixed + tw_r * kSlotWords2 * 4;
 #define NFST_LAUNCH_VIT(XM)                                                                                          \
@@ -444,8 +511,7 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   const int64_t lds = NeuLds(lat->max_rows, hid).bytes();
   // phase B reads Wh in MFMA fragment order when hid is a multiple of 64 (NFST_NEU_PACK=0: from the matrix itself)
-  static const int pack_off = getenv("NFST_NEU_PACK") && getenv("NFST_NEU_PACK")[0] == '0';
-  const int wh_packed = !pack_off && hid % 64 == 0;
+  const int wh_packed = tuning().neu_pack && hid % 64 == 0;
   if (wh_packed)
     hipLaunchKernelGGL(k_pack_mfma_b, dim3((hid * hid / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh, (int)hid,
                        reinterpret_cast<float4 *>(ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1))));
@@ -461,7 +527,7 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
     hipLaunchKernelGGL(k_backward_neural_small<LPR>, dim3(lat->n_lattices), dim3(kNeuThreads), (size_t)lds,   \
                        (hipStream_t)stream, *lat, label_x, wh, w, (int)hid, log_beta, beta_hat, ws);        \
   } while (0)
-  static const int no_small = getenv("NFST_NEU_NO_SMALL") ? 1 : 0;  // (A/B against the two-phase kernel)
+  const int no_small = !tuning().neu_small;  // (A/B against the two-phase kernel)
   // BASELINE batch, whole op: H = 8 0.52 against 1.19 ms, 16 0.58 / 1.18, 32 1.07 / 1.19; with a whole wave per
   // record (H = 64) the packed kernel has nothing to pack and loses to the two-phase one: 1.97 / 1.24
   if (hid <= 8 && !no_small) NFST_LAUNCH_NEU_SMALL(8);
@@ -499,8 +565,7 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   if (lat->fwd_slots > 0 && !lat->fwd_perm) return NFST_ERR_ARG;
   const int64_t lds = NeuGradLds(lat->max_rows, hid).bytes();
-  static const int pack_off = getenv("NFST_NEU_PACK") && getenv("NFST_NEU_PACK")[0] == '0';
-  const int wh_packed = !pack_off && hid % 64 == 0;
+  const int wh_packed = tuning().neu_pack && hid % 64 == 0;
   if (wh_packed)
     hipLaunchKernelGGL(k_pack_mfma_b, dim3((hid * hid / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh_t, (int)hid,
                        reinterpret_cast<float4 *>(ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid)));
@@ -524,7 +589,7 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
                        (hipStream_t)stream, *lat, label_x, wh_t, w, (int)hid, beta_hat, ws_fwd, g_log_beta,         \
                        g_beta_hat, gamma, grad_label_x, grad_w, ws, gx_in_lds);                                    \
   } while (0)
-  static const int no_small = getenv("NFST_NEU_NO_SMALL") ? 1 : 0;  // (A/B against the two-phase kernel)
+  const int no_small = !tuning().neu_small;  // (A/B against the two-phase kernel)
   if (hid <= 8 && !no_small) NFST_LAUNCH_NEUG_SMALL(8);
   else if (hid <= 16 && !no_small) NFST_LAUNCH_NEUG_SMALL(16);
   else if (hid <= 32 && !no_small) NFST_LAUNCH_NEUG_SMALL(32);

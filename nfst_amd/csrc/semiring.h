@@ -78,6 +78,70 @@ __device__ __forceinline__ float me_log32(float2 v) {
   return fmaf(e, 0.693145751953125f, fmaf(e, 1.42860682030941723e-6f, logf(v.x)));
 }
 
+// ---- float64 mantissas: the precise flavour of the sweeps (deep programs) ------------
+// A float32 label weight carries a relative rounding error of ~3e-8 that is the SAME at every use of the
+// label: along a path of L arcs over few distinct labels the errors add up linearly (L eps / sqrt(V)), not
+// as a random walk -- 1.5e-5 on a 900-level chain with 24 labels (tests/golden/fuzz_deep_chain.npz).  Programs
+// deeper than kPreciseTiles tiles therefore keep alpha, beta and every arc weight as (float64 mantissa,
+// int32 exponent): same semiring, same tile programs, 16 bytes per value in LDS.  v_fma_f64 / v_mul_f64 issue
+// at the float32 rate on gfx950, so the chain is as long as before; what grows is the LDS footprint.
+struct Rec64 {  // one value in LDS (16 bytes, read and written as one b128)
+  double m;
+  int e;
+  int pad;
+};
+struct ME64 {
+  double m;
+  int e;
+};
+// exp(x) = m * 2^e, m in [0.70, 1.42], relative error ~2e-16; x below -9e7 gives an exact zero
+__device__ __forceinline__ ME64 exp_split64(double x) {
+  const bool live = x > -9.0e7;
+  const double xc = fmin(live ? x : 0.0, 9.0e7);
+  const double kf = rint(xc * 1.44269504088896340736);
+  double t = fma(-kf, 6.93147180369123816490e-01, xc);  // ln 2, high part (32 bits: the product is short)
+  t = fma(-kf, 1.90821492927058770002e-10, t);          // low part
+  // exp(t), |t| <= 0.3466: degree-13 Taylor (the first term left out is 4e-18)
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, t, 1.0 / 479001600.0);
+  p = fma(p, t, 1.0 / 39916800.0);
+  p = fma(p, t, 1.0 / 3628800.0);
+  p = fma(p, t, 1.0 / 362880.0);
+  p = fma(p, t, 1.0 / 40320.0);
+  p = fma(p, t, 1.0 / 5040.0);
+  p = fma(p, t, 1.0 / 720.0);
+  p = fma(p, t, 1.0 / 120.0);
+  p = fma(p, t, 1.0 / 24.0);
+  p = fma(p, t, 1.0 / 6.0);
+  p = fma(p, t, 0.5);
+  p = fma(p, t, 1.0);
+  p = fma(p, t, 1.0);
+  ME64 r;
+  r.m = live ? p : 0.0;
+  r.e = live ? (int)kf : kEZero;
+  return r;
+}
+// (mantissa in [0.5, 1), exponent) of a sum M 2^E; an exact zero keeps the exponent that never wins a maximum
+__device__ __forceinline__ Rec64 me_pack64(double M, int E) {
+  Rec64 r;
+  r.m = __builtin_amdgcn_frexp_mant(M);
+  r.e = (M != 0.0) ? max(E + __builtin_amdgcn_frexp_exp(M), kEZero) : kEZero;
+  r.pad = 0;
+  return r;
+}
+__device__ __forceinline__ double me_log64(const Rec64 v) {
+  if (!(v.m > 0.0)) return -__builtin_huge_val();
+  return log(v.m) + (double)v.e * 0.693147180559945309417232;
+}
+__device__ __forceinline__ float2 me_f2(const Rec64 v) { return make_float2((float)v.m, __int_as_float(v.e)); }
+__device__ __forceinline__ float2 me_f2(const float2 v) { return v; }
+__device__ __forceinline__ float me_log32(const Rec64 v) { return me_log32(me_f2(v)); }
+// value types of the two flavours
+template <bool PREC> struct ValOf { typedef float2 T; };
+template <> struct ValOf<true> { typedef Rec64 T; };
+__device__ __forceinline__ void val_set(float2 &v, float m, int e) { v = make_float2(m, __int_as_float(e)); }
+__device__ __forceinline__ void val_set(Rec64 &v, float m, int e) { v.m = (double)m; v.e = e; v.pad = 0; }
+
 struct Meta {
   int row_off, n_rows, arc_off, n_arcs, fwd_off, fwd_tiles, bwd_off, bwd_tiles, sink, n_reach, depth, n_dp,
       fwd_u, bwd_u, fwd_wide, bwd_wide, fwd_slot_off, bwd_slot_off;

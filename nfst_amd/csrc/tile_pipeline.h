@@ -40,6 +40,8 @@ constexpr int kDmaAheadDeep = 8, kRawSlotsDeep = 12, kDmaAheadShared = 4, kRawSl
 constexpr int kRawWords = 64 * (1 + 4);         // raw tile for U = 4: 1280 B
 constexpr int kSlotWords = 64 * (1 + 3 * 4);    // decoded tile for U = 4: 3328 B
 constexpr int kSlotWords2 = 1024;               // ring slot of the tile-wave pipeline: 64 lanes x 64 bytes
+constexpr int kSlotWordsP = 1280;               // ... of its precise flavour (float64 mantissas): 64 lanes x 80 bytes
+constexpr int kPreciseTiles = 192;              // programs with more tiles than this run the precise flavour (semiring.h)
 // program format code (meta word, bits 0..7): 1, 2, 4 = slots per lane with 32-bit records and a
 // separate control block; 8 = the compact tile: four slots per lane, 16 bytes per lane = control
 // word + four 24-bit records (state 13 bits | label 11 bits)
@@ -702,8 +704,9 @@ __device__ __forceinline__ void tile_decoder(int n_tiles, const uint32_t *raw, i
 #ifndef NFST_X_NAP
 #define NFST_X_NAP 12
 #endif
-template <int F, int NE, int XM, bool FULL>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2; 3: their sum is staged in LDS)
+template <int F, int NE, int XM, bool FULL, bool PREC = false>  // XM: arrays of per-arc extras (0: none -- label weights only --, 1, 2; 3: their sum is staged in LDS)
 struct WeightWave {
+  static_assert(!PREC || (F == 8 && FULL && XM != 3), "precise flavour: compact tiles, tile waves, extras from HBM / L2");
   static constexpr bool GATHER = XM == 1 || XM == 2, CACHED = XM == 3;
   // FULL: the wave decodes its tiles completely -- control words and operand addresses as well -- straight
   // from HBM into the decoded ring: no loader, no staging ring, no decoder wave (tile waves of the
@@ -821,6 +824,45 @@ struct WeightWave {
       const int t = ei + min(i, n_mine - 1) * NE;
       uint32_t ctl, opoff[U], lab8[U];
       unpack(g.raw, ctl, opoff, lab8);
+      if constexpr (PREC) {
+        // the decoded tile of tile_sweep2p: values and label weights are 16-byte records (float64 mantissa, exponent):
+        // [store address | g, largest g][3 stage multipliers: the high word of 1.0 or 0][4 operand addresses]
+        // [4 weight mantissas, float64][4 weight exponents] = 80 bytes per lane
+        double om[U];
+        int oe[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const v4u tr = *(const lds_v4u *)(uintptr_t)(th_base + 2 * lab8[j]);
+          const double tm = __hiloint2double((int)tr.y, (int)tr.x);
+          if constexpr (XM == 0) {
+            om[j] = tm;
+            oe[j] = (int)tr.z;
+          } else {
+            const double xs = BOTH ? (double)g.w[GATHER ? j : 0] + (double)g.s[BOTH ? j : 0] : (double)g.w[GATHER ? j : 0];
+            const ME64 x = exp_split64(((g.valid >> j) & 1u) ? xs : 0.0);
+            om[j] = tm * x.m;
+            oe[j] = (int)tr.z + x.e;
+          }
+        }
+        while (__builtin_expect(prog_seen < t - R + 1, 0)) {  // the slot's previous tile is consumed
+          prog_seen = __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)(uintptr_t)prog_a);
+          if (prog_seen < t - R + 1) { if (R >= 8) __builtin_amdgcn_s_sleep(NFST_X_NAP); else __builtin_amdgcn_s_sleep(1); }
+        }
+        asm volatile("" ::: "memory");
+        const uint32_t sb = ring_base + (uint32_t)(t % R) * (kSlotWordsP * 4);
+        const int gl = (int)((ctl >> 20) & 7u);
+        const uint32_t dst = (((int)ctl < 0) ? 2 * (ctl & 0xffffu) + val_base : trash) | (ctl & 0x03f00000u);
+        *(lds_v4u *)(uintptr_t)(sb + lane * 16) = v4u{dst, gl > 0 ? 0x3ff00000u : 0u, gl > 1 ? 0x3ff00000u : 0u, gl > 2 ? 0x3ff00000u : 0u};
+        *(lds_v4u *)(uintptr_t)(sb + 1024 + lane * 16) = v4u{2 * opoff[0] + val_base, 2 * opoff[1 % U] + val_base, 2 * opoff[2 % U] + val_base, 2 * opoff[3 % U] + val_base};
+        *(lds_v4u *)(uintptr_t)(sb + 2048 + lane * 16) = v4u{(uint32_t)__double2loint(om[0]), (uint32_t)__double2hiint(om[0]),
+                                                             (uint32_t)__double2loint(om[1 % U]), (uint32_t)__double2hiint(om[1 % U])};
+        *(lds_v4u *)(uintptr_t)(sb + 3072 + lane * 16) = v4u{(uint32_t)__double2loint(om[2 % U]), (uint32_t)__double2hiint(om[2 % U]),
+                                                             (uint32_t)__double2loint(om[3 % U]), (uint32_t)__double2hiint(om[3 % U])};
+        *(lds_v4u *)(uintptr_t)(sb + 4096 + lane * 16) = v4u{(uint32_t)oe[0], (uint32_t)oe[1 % U], (uint32_t)oe[2 % U], (uint32_t)oe[3 % U]};
+        asm volatile("" ::: "memory");
+        *(volatile lds_u32 *)(uintptr_t)xl_a = (uint32_t)(t + 1);
+        return;
+      }
       v2f tw[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) tw[j] = *(const lds_v2f *)(uintptr_t)(th_base + lab8[j]);
@@ -1284,15 +1326,176 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
 #undef NFST_S2_STEP
 }
 
+// ---- the precise flavour of tile_sweep2: float64 mantissas (semiring.h) ---------------------------------------
+// Same loop, same hand-shakes, same ring protocol; a value is a 16-byte record (float64 mantissa, exponent), a ring
+// slot 80 bytes per lane (WeightWave<.., PREC>::process).  The terms of a tile are aligned to the stale wave-uniform
+// exponent as in tile_math3 -- with float64's range the window is 2^+-900 instead of 2^+-64 --, the segmented sum is
+// two v_mov_b32_dpp + one v_fma_f64 per stage.  Tiles with groups wider than 8 lanes (programs the packer marked
+// wide) and tiles outside the window take the exact path: maximum of exponents over the state's lanes first.
+struct Dec2P {
+  uint32_t dst;         // [0:20) LDS address of the state's record (trash for non-leader lanes) | g << 20 | largest g << 23
+  uint32_t k0, k1, k2;  // the high word of 1.0 if the state owns more than 2^s lanes, else 0
+  uint32_t opa[4];
+  double wm[4];
+  int we[4];
+};
+__device__ __forceinline__ void dec2p_fetch(uint32_t sb, int lane, Dec2P &d) {
+  const v4u h = *(const lds_v4u *)(uintptr_t)(sb + lane * 16);
+  const v4u a = *(const lds_v4u *)(uintptr_t)(sb + 1024 + lane * 16);
+  const v4u p = *(const lds_v4u *)(uintptr_t)(sb + 2048 + lane * 16);
+  const v4u q = *(const lds_v4u *)(uintptr_t)(sb + 3072 + lane * 16);
+  const v4u e = *(const lds_v4u *)(uintptr_t)(sb + 4096 + lane * 16);
+  d.dst = h.x; d.k0 = h.y; d.k1 = h.z; d.k2 = h.w;
+  d.opa[0] = a.x; d.opa[1] = a.y; d.opa[2] = a.z; d.opa[3] = a.w;
+  d.wm[0] = __hiloint2double((int)p.y, (int)p.x); d.wm[1] = __hiloint2double((int)p.w, (int)p.z);
+  d.wm[2] = __hiloint2double((int)q.y, (int)q.x); d.wm[3] = __hiloint2double((int)q.w, (int)q.z);
+  d.we[0] = (int)e.x; d.we[1] = (int)e.y; d.we[2] = (int)e.z; d.we[3] = (int)e.w;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+// segmented sum of float64 partial sums that share an exponent: a lane whose state owns 2^g lanes takes part in stages 0 .. g-1
+template <int STAGES>
+__device__ __forceinline__ double seg_sum64(double M, int g) {
+  if (STAGES >= 1) { const double o = dpp_d<0xB1>(M); M = (g >= 1) ? M + o : M; }
+  if (STAGES >= 2) { const double o = dpp_d<0x4E>(M); M = (g >= 2) ? M + o : M; }
+  if (STAGES >= 3) { const double o = dpp_d<0x141>(M); M = (g >= 3) ? M + o : M; }
+  if (STAGES >= 4) { const double o = dpp_d<0x140>(M); M = (g >= 4) ? M + o : M; }
+  if (STAGES >= 5) { const double o = __shfl_xor(M, 16); M = (g >= 5) ? M + o : M; }
+  if (STAGES >= 6) { const double o = __shfl_xor(M, 32); M = (g >= 6) ? M + o : M; }
+  return M;
+}
+__device__ __forceinline__ double ldexp_clamped(double m, int d) {  // (exponent differences may be near -2^28: zero then)
+  return ldexp(m, max(d, -2000));
+}
+__device__ __forceinline__ int tile_math3p(const Dec2P &c, const Rec64 (&vv)[4], const int ref) {  // returns this lane's largest term exponent - ref
+  const int nref = -ref;
+  double mt[4];
+  int d[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mt[j] = c.wm[j] * vv[j].m;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d[j]) : "v"(c.we[j]), "v"(vv[j].e), "s"(nref));
+  }
+  int dmax = d[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) dmax = max(dmax, d[j]);
+  constexpr int kZeroish = -(1 << 27);
+  const uint32_t wide = (c.dst >> 25) & 1u;  // the tile's largest group exceeds 8 lanes (same in every lane)
+  const uint64_t bad = __builtin_amdgcn_ballot_w64((((uint32_t)(dmax + 900) > 1800u) & (dmax > kZeroish)) | (wide != 0));
+  double M = ldexp_clamped(mt[0], d[0]);
+#pragma unroll
+  for (int j = 1; j < 4; ++j) M += ldexp_clamped(mt[j], d[j]);
+  M = fma(dpp_d<0xB1>(M), __hiloint2double((int)c.k0, 0), M);
+  M = fma(dpp_d<0x4E>(M), __hiloint2double((int)c.k1, 0), M);
+  M = fma(dpp_d<0x141>(M), __hiloint2double((int)c.k2, 0), M);
+  int E = ref;
+  if (__builtin_expect(bad != 0, 0)) {
+    const int g = (int)((c.dst >> 20) & 7u);
+    M = ldexp_clamped(mt[0], d[0] - dmax);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) M += ldexp_clamped(mt[j], d[j] - dmax);
+    E = dmax + ref;
+    const int Em = seg_max<6>(E, g);
+    M = seg_sum64<6>(ldexp_clamped(M, E - Em), g);
+    E = Em;
+  }
+  const Rec64 r = me_pack64(M, E);
+  *(lds_v4u *)(uintptr_t)(c.dst & 0xfffffu) = v4u{(uint32_t)__double2loint(r.m), (uint32_t)__double2hiint(r.m), (uint32_t)r.e, 0u};
+  return dmax;
+}
+__device__ __forceinline__ Rec64 rec64_load(uint32_t a) {
+  const v4u x = *(const lds_v4u *)(uintptr_t)a;
+  Rec64 r;
+  r.m = __hiloint2double((int)x.y, (int)x.x);
+  r.e = (int)x.z;
+  r.pad = 0;
+  return r;
+}
+template <int NEF>
+__device__ __forceinline__ void tile_sweep2p(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land, int lane) {
+  static_assert(NEF == 4, "four tile waves per sweep");
+  if (n_tiles <= 0) return;
+  constexpr uint32_t SB = kSlotWordsP * 4;
+  const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
+  const uint32_t land_a = lds_addr(land), prog_a = lds_addr(prog);
+  auto group_margin = [&]() {  // (as in tile_sweep2)
+    const v4u f = *(const volatile lds_v4u *)(uintptr_t)land_a;
+    return v2u{(uint32_t)min(min((int)f.y - 1, (int)f.z - 2), (int)f.w - 3), (uint32_t)((int)f.x - 4)};
+  };
+  auto wait_group = [&](int T, int which) {
+    for (;;) {
+      const v2u g = group_margin();
+      if (__builtin_amdgcn_readfirstlane((int)(which ? g.y : g.x)) > T) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32 *)(uintptr_t)land_a) <= 0) __builtin_amdgcn_s_sleep(1);  // tile 0
+  asm volatile("" ::: "memory");
+  uint32_t gbase = ring_base;
+  v2u margin = {0u, 0u};
+  int ref = 0;
+  int dmax0 = 0;
+  Dec2P da, db;
+  dec2p_fetch(gbase, lane, da);
+  asm volatile("" ::: "memory");
+#define NFST_S2P_STEP(K, CUR, NXT)                                                                         \
+  {                                                                                                       \
+    Rec64 vv[4];                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) vv[j] = rec64_load(CUR.opa[j]);                          \
+    asm volatile("" ::: "memory");                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    if (K == 3) {                                                                                         \
+      gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;                                  \
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.y) <= T, 0)) wait_group(T, 1);      \
+    }                                                                                                     \
+    dec2p_fetch(gbase + (K == 3 ? 0u : (K + 1) * SB), lane, NXT);                                         \
+    if (K == 1 || K == 3) margin = group_margin();                                                        \
+    asm volatile("" ::: "memory");                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    const int dm_ = tile_math3p(CUR, vv, ref);                                                            \
+    if (K == 0) dmax0 = dm_;                                                                              \
+    if (K & 1) *(volatile lds_u32 *)(uintptr_t)prog_a = (uint32_t)(T + K + 2);                            \
+    asm volatile("" ::: "memory");                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  }
+  int T = 0;
+  for (; T + 4 <= n_tiles; T += 4) {
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
+    NFST_S2P_STEP(0, da, db)
+    NFST_S2P_STEP(1, db, da)
+    NFST_S2P_STEP(2, da, db)
+    NFST_S2P_STEP(3, db, da)
+    const int e0 = __builtin_amdgcn_readfirstlane(dmax0);
+    ref = __builtin_amdgcn_readfirstlane((e0 > -(1 << 27)) ? e0 + ref : ref);
+  }
+  if (T < n_tiles) {
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
+    NFST_S2P_STEP(0, da, db)
+    if (T + 1 < n_tiles) {
+      NFST_S2P_STEP(1, db, da)
+      if (T + 2 < n_tiles) NFST_S2P_STEP(2, da, db)
+    }
+  }
+#undef NFST_S2P_STEP
+}
+
 // a weight wave's part of a sweep: compact programs were started at kernel entry (x8), the rarer
 // formats start here
-template <int NE, int XM, bool FULL>
-__device__ __forceinline__ void run_weights(WeightWave<8, NE, XM, FULL> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
+template <int NE, int XM, bool FULL, bool PREC = false>
+__device__ __forceinline__ void run_weights(WeightWave<8, NE, XM, FULL, PREC> &x8, int F, const uint32_t *prog_words, const int32_t *perm,
                                             int n_tiles, const Extra ex, int ei, uint32_t *ring, int R, int *flags,
                                             const float2 *th, const float2 *val, bool v2, uint32_t trash, uint32_t xc_base, int xc_first,
                                             int lane) {
   const int *prog = flags;
   int *xland = flags + 4;
+  if constexpr (PREC) {
+    x8.run(ring, R, prog, xland, th, val, v2, trash, xc_base, xc_first, lane);
+    return;
+  }
   if (F == 8 || FULL) {  // (tile waves run all-compact batches only)
     x8.run(ring, R, prog, xland, th, val, v2, trash, xc_base, xc_first, lane);
   } else if (F == 4) {
@@ -1324,5 +1527,17 @@ __device__ __forceinline__ void load_theta(float2 *th, const float *theta, int64
   if (tid == 0) {
     th[V] = make_float2(0.0f, __int_as_float(kEZero));  // the null label of empty slots
     th[V + 1] = make_float2(0.5f, __int_as_float(1));       // weight one: the carry record of a continuation piece
+  }
+}
+__device__ __forceinline__ void load_theta(Rec64 *th, const float *theta, int64_t stride, int b,
+                                           int V, int tid, int nt, float first) {
+  const float *t = theta + (size_t)stride * b;
+  for (int l = tid; l < V; l += nt) {
+    const ME64 x = exp_split64((double)(l == tid ? first : t[l]));
+    th[l].m = x.m; th[l].e = x.e; th[l].pad = 0;
+  }
+  if (tid == 0) {
+    th[V].m = 0.0; th[V].e = kEZero; th[V].pad = 0;     // the null label of empty slots
+    th[V + 1].m = 0.5; th[V + 1].e = 1; th[V + 1].pad = 0;  // weight one: the carry record of a continuation piece
   }
 }

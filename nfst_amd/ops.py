@@ -46,6 +46,10 @@ def _scores(lat: LatticeBatch, theta: torch.Tensor, arc_scores: Optional[torch.T
         arc_scores = arc_scores.to(device=lat.device, dtype=torch.float32).contiguous()
         if arc_scores.shape != (lat.total_arcs,):
             raise ValueError(f"arc_scores must be [{lat.total_arcs}] in canonical arc order")
+        if arc_scores.data_ptr() % 16:
+            # a slice or split of a larger score tensor is contiguous but starts anywhere; the kernels read
+            # per-arc scores 16 bytes at a time (nfst_forward_backward refuses a misaligned base)
+            arc_scores = arc_scores.clone()
     return _lib.Scores(theta.data_ptr(), stride, _ptr(arc_scores), None, 0), (theta, arc_scores)
 
 

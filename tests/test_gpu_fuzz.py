@@ -1,0 +1,190 @@
+"""Randomised parity of the sweep kernels against the oracle (``-m gpu``, through the C ABI).
+
+Round 2 ran this as a script beside the tests and it found a miss the test suite did not hold: log Z off by 1.56e-5 on
+a 900-level chain with 24 labels, table weights and caller scores (seed 1, batch 135, lattice 40; kept as
+``tests/golden/fuzz_deep_chain.npz``).  The cause is not the depth of the float32 arithmetic as such: a float32 label
+weight carries ONE rounding error that every use of the label repeats, so along L arcs over V labels the error grows
+like L eps / sqrt(V) instead of sqrt(L) eps (predicted from the posterior label counts: 1.45e-5).  Programs deeper than
+``kPreciseTiles`` tiles now run the precise flavour (float64 mantissas); here every batch is held
+to the plain 1e-5 with no exception.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from nfst_amd import ops, synth, _lib
+from nfst_amd.lattice import LatticeBatch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+_WORST = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if _WORST and os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "fuzz_errors.json"), "w") as f:
+            json.dump(dict(sorted(_WORST.items())), f, indent=1)
+
+
+def _rec(tag, err):
+    _WORST[tag] = max(_WORST.get(tag, 0.0), float(err))
+    return float(err)
+
+
+def test_deep_chain_case_of_round_2(dev):
+    """The lattice the round-2 fuzz run missed on: 900 levels, 24 labels, table weights + caller scores."""
+    d = np.load(os.path.join(GOLDEN, "fuzz_deep_chain.npz"))
+    l = synth.SynthLattice(int(d["n_rows"]), int(d["vocab"]), d["src"], d["label"], d["dst"], d["weight"])
+    theta, asc = d["theta"], d["arc_scores"]
+    sc = theta[l.label].astype(np.float64) + l.weight.astype(np.float64) + asc.astype(np.float64)
+    o = O.forward_backward(l.n_rows, l.src, l.dst, sc)
+    th, t = torch.from_numpy(theta), torch.from_numpy(asc)
+    for gm in (0, 2):  # (the fuzz batch was packed with wide groups)
+        lat = LatticeBatch.from_synth([l], device=dev, group_mode=gm)
+        assert int(lat.max_tiles) > 192
+        r = ops.forward_backward(lat, th, arc_scores=t)
+        b = ops.backward(lat, th, arc_scores=t)
+        assert _rec("deep_chain_logz", abs(float(r.logz64[0]) - o["logZ"])) <= 1e-8, gm  # float64 mantissas: ~1e-12 expected
+        assert abs(float(b.logz64[0]) - o["logZ"]) <= 1e-8, gm
+        assert np.max(np.abs(r.posterior.cpu().numpy() - o["posterior"])) <= 2e-6
+        # the float32 flavour on the same lattice: what the precise flavour is for (reported, not asserted tight)
+        with _lib.tuning(precise=0):
+            r32 = ops.forward_backward(lat, th, arc_scores=t)
+        e32 = _rec("deep_chain_logz_float32_flavour", abs(float(r32.logz64[0]) - o["logZ"]))
+        assert e32 <= 1e-4, "the float32 flavour is off by far more than rounding explains"
+
+
+def _draw_batch(rng):
+    B = int(rng.integers(1, 48))
+    V = int(rng.choice([24, 40, 256, 700]))
+    weighted = bool(rng.integers(0, 2))
+    lats = []
+    for _ in range(B):
+        n = int(rng.choice([4, 5, 6, 9, 17, 40, 90, 200, 450, 900, 1500]))
+        md = min(int(rng.choice([8, 24, 60])), (V - 12) // 2)
+        for _attempt in range(50):  # (the generator refuses a state whose arcs outnumber the labels: draw again)
+            try:
+                lats.append(synth.layered_lattice(int(rng.integers(1, 1 << 30)), n_states=n,
+                                                  avg_degree=min(float(rng.choice([1.5, 3.0, 6.0, 12.0])), md / 2), vocab=V,
+                                                  width=int(rng.choice([1, 2, 4, 8, 16, 32])), span=int(rng.choice([1, 2, 4, 8])),
+                                                  max_degree=md, weighted=weighted))
+                break
+            except AssertionError:
+                continue
+    return lats, V, weighted
+
+
+@pytest.mark.parametrize("seed", list(range(56)))
+def test_fuzz_sweeps_against_oracle(dev, seed):
+    """Random batch sizes, lattice sizes (4 .. 1500 states), widths, spans, degrees, vocabularies, group modes, table
+    weights, caller scores.  Per batch: (i) the default launch (precise flavour for deep programs) against the oracle
+    at 1e-5, log Z of forward-backward and of the beta-only sweep, posteriors at 1e-5; (ii) with the precise flavour
+    off, tile waves against the loader / decoder / sweep pipeline: same bits; (iii) Viterbi of the two pipelines."""
+    rng = np.random.default_rng(1000 + seed)
+    for it in range(7):
+        lats, V, weighted = _draw_batch(rng)
+        B = len(lats)
+        lat = LatticeBatch.from_synth(lats, device=dev, group_mode=int(rng.choice([0, 0, 0, 1, 2])))
+        theta = synth.label_scores(int(rng.integers(0, 1000)), V, mean=float(rng.choice([-2.3, 0.0, -8.0])), std=float(rng.choice([0.5, 2.0])))
+        th = torch.from_numpy(theta)
+        asc = rng.normal(0.0, 0.5, size=lat.total_arcs).astype(np.float32) if rng.integers(0, 2) else None
+        t = None if asc is None else torch.from_numpy(asc)
+        fa, ba = ops.forward_backward(lat, th, arc_scores=t), ops.backward(lat, th, arc_scores=t)
+        res = {}
+        for tw in (1, 0):
+            with _lib.tuning(tw=tw, precise=0):
+                res[tw] = (ops.forward_backward(lat, th, arc_scores=t), ops.backward(lat, th, arc_scores=t), ops.viterbi(lat, th, arc_scores=t))
+        torch.cuda.synchronize()
+        (f1, b1, v1), (f0, b0, v0) = res[1], res[0]
+        assert torch.equal(f1.logz64, f0.logz64) and torch.equal(f1.logalpha, f0.logalpha) and torch.equal(f1.logbeta, f0.logbeta), (seed, it)
+        assert torch.equal(b1.logz64, b0.logz64) and torch.equal(b1.logbeta, b0.logbeta), (seed, it)
+        if asc is None and not weighted:  # (with extras the two Viterbi kernels add an arc's float32 addends in different orders)
+            assert torch.equal(v1.best, v0.best) and torch.equal(v1.paths, v0.paths) and torch.equal(v1.lengths, v0.lengths), (seed, it)
+        else:
+            assert torch.allclose(v1.best, v0.best, rtol=1e-5, atol=1e-5), (seed, it)
+        # the precise flavour moves log Z by no more than the float32 flavour's rounding
+        assert float((fa.logz64 - f1.logz64).abs().max()) <= 1e-4, (seed, it)
+        deep = int(lat.max_tiles) > 192
+        z, zb, post = fa.logz64.cpu().numpy(), ba.logz64.cpu().numpy(), fa.posterior.cpu().numpy()
+        for b in rng.choice(B, size=min(B, 6), replace=False):
+            l = lats[b]
+            a0 = int(lat.arc_off[b])
+            sc = theta[l.label].astype(np.float64)
+            if l.weight is not None:
+                sc = sc + l.weight
+            if asc is not None:
+                sc = sc + asc[a0:a0 + l.n_arcs]
+            o = O.forward_backward(l.n_rows, l.src, l.dst, sc)
+            tag = "deep" if deep else "shallow"
+            assert _rec(f"fuzz_logz_{tag}", abs(z[b] - o["logZ"])) <= TOL, (seed, it, int(b), l.n_rows, int(lat.depth[b]), V, weighted, asc is not None)
+            assert _rec(f"fuzz_logz_beta_only_{tag}", abs(zb[b] - o["logZ"])) <= TOL, (seed, it, int(b))
+            assert _rec(f"fuzz_posterior_{tag}", np.max(np.abs(post[a0:a0 + l.n_arcs] - o["posterior"]))) <= 1e-5, (seed, it, int(b))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_posterior_sampler(dev, seed):
+    """Random batches (sizes, widths, degrees up to 60 arcs per state, table weights, caller scores, K): the ways
+    ``k_sample`` reads a lattice against each other, every walk an accepting path with log q = score - log Z
+    (Sampler.sample with the exact posterior as proposal, /root/reference/src/modules/samplers.py:137-335)."""
+    rng = np.random.default_rng(2000 + seed)
+    worst_q = 0.0
+    for it in range(8):
+        B = int(rng.integers(1, 12))
+        V = int(rng.choice([24, 40, 256]))
+        weighted = bool(rng.integers(0, 2))
+        lats = []
+        for _ in range(B):
+            n = int(rng.choice([4, 5, 6, 9, 17, 40, 90, 200, 450, 900, 2500]))
+            md = min(int(rng.choice([8, 24, 60])), (V - 12) // 2)
+            for _attempt in range(50):
+                try:
+                    lats.append(synth.layered_lattice(int(rng.integers(1, 1 << 30)), n_states=n,
+                                                      avg_degree=min(float(rng.choice([1.5, 3.0, 6.0, 12.0, 20.0])), md / 2), vocab=V,
+                                                      width=int(rng.choice([1, 2, 4, 8, 16, 32])), span=int(rng.choice([1, 2, 4, 8])),
+                                                      max_degree=md, weighted=weighted))
+                    break
+                except AssertionError:
+                    continue
+        B = len(lats)
+        lat = LatticeBatch.from_synth(lats, device=dev)
+        theta = synth.label_scores(int(rng.integers(0, 1000)), V, mean=float(rng.choice([-2.3, 0.0, -8.0])), std=float(rng.choice([0.5, 2.0])))
+        th = torch.from_numpy(theta)
+        asc = rng.normal(0.0, 0.5, size=lat.total_arcs).astype(np.float32) if rng.integers(0, 2) else None
+        t = None if asc is None else torch.from_numpy(asc)
+        K = int(rng.choice([1, 3, 16, 40, 64, 100]))
+        T = int(lat.depth.max()) + 1
+        u = torch.from_numpy(rng.random((B, K, T)).astype(np.float32))
+        a = ops.sample_paths(lat, th, K, arc_scores=t, max_len=T, uniforms=u)
+        b = ops.sample_paths(lat, th, K, arc_scores=t, max_len=T, uniforms=u, want_arcs=False)
+        c = ops.sample_paths(lat, th, K, arc_scores=t, seed=it)
+        c2 = ops.sample_paths(lat, th, K, arc_scores=t, seed=it)
+        torch.cuda.synchronize()
+        assert torch.equal(c.paths, c2.paths) and torch.equal(c.arcs, c2.arcs), (seed, it)
+        same = float((a.paths == b.paths).all(dim=2).float().mean())
+        assert same > 0.97, (seed, it, same)  # (the two staged modes round the CDF differently: walks may part at a boundary)
+        for res in (a, c):
+            arcs, lens, logq = res.arcs.cpu().numpy(), res.lengths.cpu().numpy(), res.logq.cpu().numpy()
+            for bb in rng.choice(B, size=min(B, 3), replace=False):
+                l = lats[bb]
+                a0 = int(lat.arc_off[bb])
+                sc = theta[l.label].astype(np.float64)
+                if l.weight is not None:
+                    sc = sc + l.weight
+                if asc is not None:
+                    sc = sc + asc[a0:a0 + l.n_arcs]
+                o = O.forward_backward(l.n_rows, l.src, l.dst, sc)
+                for k in range(0, K, max(1, K // 5)):
+                    p = arcs[bb, k, :lens[bb, k]] - a0
+                    assert lens[bb, k] > 0 and l.src[p[0]] == 0 and l.dst[p[-1]] == l.n_rows - 1 and np.all(l.dst[p[:-1]] == l.src[p[1:]]), (seed, it, bb, k)
+                    ref = sc[p].sum() - o["logZ"]
+                    worst_q = max(worst_q, abs(ref - logq[bb, k]) - 6e-8 * abs(ref))  # (beyond the float32 rounding of log q itself)
+    assert _rec("fuzz_sampler_logq_beyond_f32_rounding", worst_q) <= 2e-5

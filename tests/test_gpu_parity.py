@@ -226,6 +226,30 @@ def test_weighted_tables_and_arc_scores(dev):
         assert np.max(np.abs(r.posterior.cpu().numpy()[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
 
 
+def test_arc_scores_taken_as_a_slice_of_a_larger_tensor(dev):
+    """``arc_scores`` that is a view into a larger score tensor (contiguous, but its first element is not
+    16-byte aligned) gives the bits of an aligned copy: every op that takes per-arc scores."""
+    lats = [synth.layered_lattice(60 + i, n_states=150, avg_degree=5.0, vocab=48, width=6, span=3, weighted=(i % 2 == 0)) for i in range(2)]
+    for group in ([lats[0]], [lats[1]]):
+        lat = LatticeBatch.from_synth(group, device=dev)
+        th = torch.from_numpy(synth.label_scores(3, 48))
+        big = torch.randn(lat.total_arcs + 11, device=dev) * 0.3
+        for off in (1, 3, 5):
+            view = big[off:off + lat.total_arcs]
+            assert view.data_ptr() % 16 != 0
+            ref = view.clone()
+            a, b = ops.forward_backward(lat, th, arc_scores=view), ops.forward_backward(lat, th, arc_scores=ref)
+            assert torch.equal(a.logz64, b.logz64) and torch.equal(a.posterior, b.posterior) and torch.equal(a.logalpha, b.logalpha)
+            assert torch.equal(ops.backward(lat, th, arc_scores=view).logz64, ops.backward(lat, th, arc_scores=ref).logz64)
+            va, vb = ops.viterbi(lat, th, arc_scores=view), ops.viterbi(lat, th, arc_scores=ref)
+            assert torch.equal(va.best, vb.best) and torch.equal(va.paths, vb.paths)
+            sa, sb = ops.sample_paths(lat, th, 4, arc_scores=view, seed=5), ops.sample_paths(lat, th, 4, arc_scores=ref, seed=5)
+            assert torch.equal(sa.paths, sb.paths) and torch.equal(sa.logq, sb.logq)
+            assert torch.equal(ops.gather_label_scores(lat, th, arc_scores=view), ops.gather_label_scores(lat, th, arc_scores=ref))
+            z = ops.log_z(lat, th, view.clone().requires_grad_(True))
+            assert torch.equal(z.detach(), a.logz)
+
+
 def test_extreme_scores_do_not_overflow(dev):
     """The reference's probability-domain beta overflows float32 once log Z > 88
     (SURVEY.md section 6); the (mantissa, exponent) semiring must not."""
@@ -1131,10 +1155,10 @@ def test_beta_neural_grad_funnels(dev):
 
 
 # ----------------------------------------------------------------------------- tile waves (one lattice per CU)
-def test_tile_waves_short_programs_and_flavour_bits(dev, monkeypatch):
+def test_tile_waves_short_programs_and_flavour_bits(dev):
     """The tile-wave kernels (all-compact batches, at most one lattice per CU) on programs shorter than the
     four tile waves of a sweep, programs of 1 .. 9 tiles, wide groups, table weights + caller scores, and
-    beside them the loader / decoder / sweep pipeline (NFST_TW=0): same bits for log Z, the row outputs and
+    beside them the loader / decoder / sweep pipeline (switch tw = 0): same bits for log Z, the row outputs and
     the posteriors, oracle parity for both, beta-only sweep included."""
     V = 40
     lats = []
@@ -1155,11 +1179,10 @@ def test_tile_waves_short_programs_and_flavour_bits(dev, monkeypatch):
         for scores in (None, asc):
             t = None if scores is None else torch.from_numpy(scores)
             res = {}
-            for tw in ("1", "0"):
-                monkeypatch.setenv("NFST_TW", tw)
-                res[tw] = (ops.forward_backward(lat, th, arc_scores=t), ops.backward(lat, th, arc_scores=t))
-            monkeypatch.delenv("NFST_TW")
-            (fa, ba), (fb, bb) = res["1"], res["0"]
+            for tw in (1, 0):
+                with _lib.tuning(tw=tw):
+                    res[tw] = (ops.forward_backward(lat, th, arc_scores=t), ops.backward(lat, th, arc_scores=t))
+            (fa, ba), (fb, bb) = res[1], res[0]
             assert torch.equal(fa.logz64, fb.logz64) and torch.equal(fa.logalpha, fb.logalpha) and torch.equal(fa.logbeta, fb.logbeta)
             assert torch.equal(ba.logz64, bb.logz64) and torch.equal(ba.logbeta, bb.logbeta)
             assert float(torch.max(torch.abs(fa.posterior - fb.posterior))) <= 2e-7  # (the posterior pass is the same code)
