@@ -796,7 +796,10 @@ struct WeightWave {
     last = max(n_tiles - 1, 0);
     bw = ex.arc_w ? ex.arc_w : ex.arc_scores;
     bs = ex.arc_scores;
-    if (n_tiles <= 0) { n_mine = 0; return; }
+    // a wave without a tile of its own loads nothing: "tile ei" of a program shorter than ei tiles lies behind the
+    // program -- for the batch's last lattice behind the slot -> arc map itself, and whatever is there would be used
+    // as an arc index by the gathers (a memory fault in round 3's fuzz run: 3-tile program, table weights)
+    if (n_tiles <= 0 || n_mine <= 0) { n_mine = 0; return; }
     p0 = ld_tile(0, lane); p1 = ld_tile(1, lane); p2 = ld_tile(2, lane);
   }
   __device__ __forceinline__ void start_gathers(int lane) {
