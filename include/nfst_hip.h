@@ -196,6 +196,30 @@ int nfst_pack_arcs(const int32_t *n_rows, const int64_t *arc_off, const int32_t 
                    int32_t n_lattices, int32_t vocab, const nfst_pack_opts *opts,
                    nfst_packed **out, int32_t *err_lattice);
 
+/*
+ * Packed batches on the host (sidecar files, DataLoader workers).
+ *
+ * nfst_validate_batch: everything a kernel turns into an address without looking -- offsets and counts of the meta
+ * records, row pointers, the state / label / arc ids of the canonical arrays, of every tile's control words and records
+ * and of the slot -> arc maps -- is inside the batch's arrays and inside the LDS rows the launchers size from max_rows
+ * and vocab.  Host pointers, O(words of the batch).  A batch read back from a file is checked with this before it is
+ * ever handed to a kernel (LatticeBatch.load); err_lattice (may be NULL) receives the offending lattice.
+ *
+ * nfst_crc32c: CRC-32C of a byte range (the checksum stored per array in sidecar files); chain calls through `seed`
+ * (0 for the first).
+ *
+ * nfst_concat_sizes / nfst_concat_packed: one batch from already packed ones without running the packer again -- the
+ * collate step of a loader that packs every example once (util/dataset_reader.py:175-186 pads and stacks dense tables
+ * instead).  concat_sizes fills the scalar fields of *total; the caller allocates the arrays (ordinary or page-locked
+ * host memory), stores their addresses in *total and calls concat_packed, which writes through those pointers:
+ * memcpy + offset fix-ups, n_threads host threads over the parts (0 = hardware).  The parts must agree in vocabulary
+ * and in being weighted; the result is bit-identical to packing the lattices as one batch.
+ */
+int nfst_validate_batch(const nfst_batch *lat, int32_t *err_lattice);
+uint32_t nfst_crc32c(const void *data, int64_t n_bytes, uint32_t seed);
+int nfst_concat_sizes(const nfst_batch *parts, int32_t n_parts, nfst_batch *total);
+int nfst_concat_packed(const nfst_batch *parts, int32_t n_parts, const nfst_batch *out, int32_t n_threads);
+
 /* view of the arrays owned by a packed batch (host pointers, valid until free) */
 int nfst_packed_view(const nfst_packed *p, nfst_batch *view);
 void nfst_packed_free(nfst_packed *p);
@@ -319,6 +343,10 @@ int nfst_beta_logits(const nfst_batch *lat, const float *values, const int64_t *
  *           where accumulated > insert_threshold             (if insert_threshold > 0; 663-669)
  *       scores -= vocab_use * length_penalty                  (if 0 < length_threshold < length; 671-677)
  *     `length` is the step's metadata["length"] (1 at the first step).
+ *   not_pad: device int32 word (zeroed by the caller): the launch adds the number of walkers whose symbol is
+ *     not `pad` -- zero means "every walker has ended" (Sampler.all_reached_eos, samplers.py:288-290) without a
+ *     reduction kernel; a sampling loop reads it every few steps instead of synchronising with the device at
+ *     every step.
  */
 typedef struct nfst_step_extras {
   const int64_t *value_state;
@@ -330,6 +358,7 @@ typedef struct nfst_step_extras {
   int32_t length_threshold;
   float length_penalty;
   int32_t length;
+  int32_t *not_pad;
 } nfst_step_extras;
 
 /*

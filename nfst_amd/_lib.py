@@ -57,7 +57,8 @@ class Scores(C.Structure):
 class StepExtras(C.Structure):
     _fields_ = [("value_state", C.c_void_p), ("accumulated", C.c_void_p), ("vocab_use", C.c_void_p),
                 ("insertion_mark", C.c_int32), ("insert_threshold", C.c_int32), ("insert_penalty", C.c_float),
-                ("length_threshold", C.c_int32), ("length_penalty", C.c_float), ("length", C.c_int32)]
+                ("length_threshold", C.c_int32), ("length_penalty", C.c_float), ("length", C.c_int32),
+                ("not_pad", C.c_void_p)]
 
 
 class PackOpts(C.Structure):
@@ -82,6 +83,10 @@ def _load():
         "nfst_pack_dense": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
         "nfst_pack_arcs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
         "nfst_packed_view": (C.c_int, [vp, BP]),
+        "nfst_validate_batch": (C.c_int, [BP, C.POINTER(i32)]),
+        "nfst_crc32c": (C.c_uint32, [vp, i64, C.c_uint32]),
+        "nfst_concat_sizes": (C.c_int, [BP, i32, BP]),
+        "nfst_concat_packed": (C.c_int, [BP, i32, BP, i32]),
         "nfst_packed_free": (None, [vp]),
         "nfst_lds_bytes": (i64, [BP]),
         "nfst_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp]),

@@ -408,6 +408,212 @@ static int finish(std::vector<Lat> &lats, int vocab, bool weighted, const Opts &
   return NFST_OK;
 }
 
+// ---------------------------------------------------------------- packed batches on the host: check, checksum, concatenate
+namespace {
+// CRC-32C (Castagnoli): the SSE4.2 instruction where the CPU has it (8 bytes per step, three streams interleaved
+// would be faster still; this runs at ~8 GB/s), a table otherwise
+uint32_t crc32c_table_at(uint32_t i) {
+  uint32_t c = i;
+  for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+  return c;
+}
+uint32_t crc32c_soft(uint32_t crc, const uint8_t *p, size_t n) {
+  static uint32_t table[256];
+  static std::atomic<int> ready(0);
+  if (!ready.load(std::memory_order_acquire)) {
+    for (uint32_t i = 0; i < 256; ++i) table[i] = crc32c_table_at(i);
+    ready.store(1, std::memory_order_release);
+  }
+  for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+  return crc;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) uint32_t crc32c_hw(uint32_t crc, const uint8_t *p, size_t n) {
+  uint64_t c = crc;
+  while (n && ((uintptr_t)p & 7)) { c = __builtin_ia32_crc32qi((uint32_t)c, *p++); --n; }
+  for (; n >= 8; n -= 8, p += 8) { uint64_t v; std::memcpy(&v, p, 8); c = __builtin_ia32_crc32di(c, v); }
+  while (n--) c = __builtin_ia32_crc32qi((uint32_t)c, *p++);
+  return (uint32_t)c;
+}
+#endif
+}  // namespace
+
+extern "C" uint32_t nfst_crc32c(const void *data, int64_t n_bytes, uint32_t seed) {
+  if (!data || n_bytes <= 0) return seed;
+  uint32_t crc = ~seed;
+#if defined(__x86_64__)
+  if (__builtin_cpu_supports("sse4.2")) return ~crc32c_hw(crc, (const uint8_t *)data, (size_t)n_bytes);
+#endif
+  return ~crc32c_soft(crc, (const uint8_t *)data, (size_t)n_bytes);
+}
+
+// Everything a kernel turns into an address without looking: offsets and counts of the meta records, row pointers,
+// state / label / arc ids of the canonical arrays, of every tile's control words and records, of the slot -> arc maps.
+// Host pointers.  O(words of the batch).  A sidecar file that passes this cannot make a kernel read or write outside
+// the batch's arrays or outside the LDS rows the launchers size from max_rows / vocab.
+extern "C" int nfst_validate_batch(const nfst_batch *lat, int32_t *err_lattice) {
+  if (err_lattice) *err_lattice = -1;
+  if (!lat || lat->n_lattices <= 0 || lat->vocab <= 0 || lat->vocab > NFST_MAX_VOCAB || lat->max_rows <= 0 || lat->max_rows > NFST_MAX_ROWS)
+    return NFST_ERR_ARG;
+  if (!lat->meta || !lat->row_ptr || !lat->fwd_stream || !lat->bwd_stream || !lat->arc_sd || !lat->arc_l16) return NFST_ERR_ARG;
+  if (lat->total_arcs > 0 && (!lat->arc_src || !lat->arc_dst || !lat->arc_label)) return NFST_ERR_ARG;
+  if ((lat->fwd_slots > 0 && !lat->fwd_perm) || (lat->bwd_slots > 0 && !lat->bwd_perm) || (lat->weighted && !lat->arc_w)) return NFST_ERR_ARG;
+  if (lat->total_rows < 0 || lat->total_arcs < 0 || lat->fwd_words < 512 || lat->bwd_words < 512 || lat->fwd_slots < 0 || lat->bwd_slots < 0) return NFST_ERR_ARG;
+  const int B = lat->n_lattices, V = lat->vocab;
+  bool all_compact = true;
+  int64_t max_arcs = 0, dp_total = 0;
+  for (int b = 0; b < B; ++b) {
+    auto fail = [&](int code) { if (err_lattice) *err_lattice = b; return code; };
+    const int32_t *m = lat->meta + (size_t)b * NFST_META_WORDS;
+    const int64_t row_off = m[NFST_META_ROW_OFF], n = m[NFST_META_N_ROWS], a0 = m[NFST_META_ARC_OFF], na = m[NFST_META_N_ARCS];
+    if (row_off < 0 || n <= 0 || n > lat->max_rows || row_off + n > lat->total_rows) return fail(NFST_ERR_INDEX);
+    if (a0 < 0 || na < 0 || a0 + na > lat->total_arcs) return fail(NFST_ERR_INDEX);
+    if (m[NFST_META_SINK] < 0 || m[NFST_META_SINK] >= n || m[NFST_META_N_REACH] < 1 || m[NFST_META_N_REACH] > n) return fail(NFST_ERR_INDEX);
+    if (m[NFST_META_N_DP] < 0 || m[NFST_META_N_DP] > na || m[NFST_META_DEPTH] < 0 || m[NFST_META_DEPTH] >= n) return fail(NFST_ERR_INDEX);
+    max_arcs = std::max(max_arcs, na);
+    dp_total += m[NFST_META_N_DP];
+    // canonical arcs
+    const int32_t *rp = lat->row_ptr + row_off + b;
+    if (rp[0] != a0 || rp[n] != a0 + na) return fail(NFST_ERR_INDEX);
+    for (int64_t s = 0; s < n; ++s)
+      if (rp[s + 1] < rp[s]) return fail(NFST_ERR_INDEX);
+    for (int64_t a = a0; a < a0 + na; ++a) {
+      const int32_t s = lat->arc_src[a], d = lat->arc_dst[a], l = lat->arc_label[a];
+      if (s < 0 || s >= n || d < 0 || d >= n || l < 0 || l >= V) return fail(NFST_ERR_INDEX);
+      if (a < rp[s] || a >= rp[s + 1]) return fail(NFST_ERR_INDEX);
+      if (lat->arc_sd[a] != ((uint32_t)s | ((uint32_t)d << 16)) || lat->arc_l16[a] != (uint16_t)l) return fail(NFST_ERR_INDEX);
+    }
+    // tile programs and slot -> arc maps
+    for (int dir = 0; dir < 2; ++dir) {
+      const int64_t off = m[dir ? NFST_META_BWD_OFF : NFST_META_FWD_OFF], tiles = m[dir ? NFST_META_BWD_TILES : NFST_META_FWD_TILES];
+      const int code = m[dir ? NFST_META_BWD_U : NFST_META_FWD_U] & 0xff;
+      const int64_t slot_off = m[dir ? NFST_META_BWD_SLOT_OFF : NFST_META_FWD_SLOT_OFF];
+      const int64_t words = dir ? lat->bwd_words : lat->fwd_words, slots = dir ? lat->bwd_slots : lat->fwd_slots;
+      const uint32_t *stream = dir ? lat->bwd_stream : lat->fwd_stream;
+      const int32_t *perm = dir ? lat->bwd_perm : lat->fwd_perm;
+      if (code != 1 && code != 2 && code != 4 && code != 8) return fail(NFST_ERR_ARG);
+      all_compact = all_compact && code == 8;
+      const int U = code == 8 ? 4 : code, tw = code == 8 ? 256 : 64 * (1 + code);
+      if (tiles < 0 || tiles > lat->max_tiles || off < 0 || (off & 63) || off + tiles * tw > words - 512) return fail(NFST_ERR_INDEX);
+      if (slot_off < 0 || slot_off + tiles * 64 * U > slots) return fail(NFST_ERR_INDEX);
+      const uint32_t max_state = (uint32_t)lat->max_rows, max_label = (uint32_t)V + 1;
+      for (int64_t t = 0; t < tiles; ++t) {
+        const uint32_t *w = stream + off + t * tw;
+        for (int l = 0; l < 64; ++l) {
+          uint32_t ctl, rec_state[4], rec_label[4];
+          if (code == 8) {
+            const uint32_t *x = w + 4 * l;
+            ctl = x[0];
+            const uint32_t r[4] = {x[1] & 0xffffffu, ((x[1] >> 24) | (x[2] << 8)) & 0xffffffu, ((x[2] >> 16) | (x[3] << 16)) & 0xffffffu, x[3] >> 8};
+            for (int j = 0; j < 4; ++j) { rec_state[j] = r[j] & 0x1fffu; rec_label[j] = r[j] >> 13; }
+          } else {
+            ctl = w[l];
+            for (int j = 0; j < U; ++j) { const uint32_t r = w[64 + l * U + j]; rec_state[j] = (r & 0xffffu) >> 3; rec_label[j] = r >> 16; }
+          }
+          const uint32_t g = (ctl >> 20) & 7u, gmax = (ctl >> 23) & 7u;
+          if (((ctl & 0xffffu) >> 3) >= max_state || (ctl & 7u) || g > 6 || gmax > 6 || g > gmax) return fail(NFST_ERR_INDEX);
+          for (int j = 0; j < U; ++j)
+            if (rec_state[j] >= max_state || rec_label[j] > max_label) return fail(NFST_ERR_INDEX);
+        }
+        const int32_t *pm = perm + slot_off + t * 64 * U;
+        for (int q = 0; q < 64 * U; ++q)
+          if (pm[q] != -1 && (pm[q] < a0 || pm[q] >= a0 + na)) return fail(NFST_ERR_INDEX);
+      }
+    }
+  }
+  if (((lat->reserved0 & NFST_BATCH_ALL_COMPACT) != 0) && !all_compact) return NFST_ERR_ARG;
+  const int64_t rec_max = ((int64_t)lat->reserved0 >> NFST_BATCH_MAX_ARCS_SHIFT) & NFST_BATCH_MAX_ARCS_CAP;
+  if (rec_max < std::min<int64_t>(max_arcs, NFST_BATCH_MAX_ARCS_CAP)) return NFST_ERR_ARG;  // (the launchers size LDS-resident per-arc data with it)
+  if (dp_total != lat->total_dp_arcs) return NFST_ERR_ARG;
+  return NFST_OK;
+}
+
+// Concatenation of packed batches without running the packer again (pack every example once, build a step's
+// batch from sidecars): memcpy + offset fix-ups, parallel over the parts.  nfst_concat_sizes fills the scalar fields of
+// *total; the caller allocates the arrays (ordinary or page-locked host memory), stores their addresses in *total and
+// calls nfst_concat_packed, which writes through them.
+extern "C" int nfst_concat_sizes(const nfst_batch *parts, int32_t n_parts, nfst_batch *total) {
+  if (!parts || n_parts <= 0 || !total) return NFST_ERR_ARG;
+  nfst_batch t{};
+  t.vocab = parts[0].vocab; t.weighted = parts[0].weighted;
+  int all_compact = 1;
+  int64_t max_arcs = 0;
+  const int64_t slack = 512;
+  for (int i = 0; i < n_parts; ++i) {
+    const nfst_batch &p = parts[i];
+    if (p.vocab != t.vocab || p.weighted != t.weighted || p.n_lattices <= 0 || p.fwd_words < slack || p.bwd_words < slack) return NFST_ERR_ARG;
+    t.n_lattices += p.n_lattices; t.max_rows = std::max(t.max_rows, p.max_rows); t.max_tiles = std::max(t.max_tiles, p.max_tiles);
+    t.total_rows += p.total_rows; t.total_arcs += p.total_arcs; t.total_dp_arcs += p.total_dp_arcs;
+    t.fwd_words += p.fwd_words - slack; t.bwd_words += p.bwd_words - slack; t.fwd_slots += p.fwd_slots; t.bwd_slots += p.bwd_slots;
+    all_compact &= (p.reserved0 & NFST_BATCH_ALL_COMPACT) ? 1 : 0;
+    max_arcs = std::max<int64_t>(max_arcs, ((int64_t)p.reserved0 >> NFST_BATCH_MAX_ARCS_SHIFT) & NFST_BATCH_MAX_ARCS_CAP);
+  }
+  if (std::max({t.total_arcs, t.fwd_words, t.bwd_words, t.fwd_slots, t.bwd_slots, t.total_rows}) > 0x7ffff000ll) return NFST_ERR_LIMIT;
+  t.fwd_words += slack; t.bwd_words += slack;
+  t.reserved0 = (all_compact ? NFST_BATCH_ALL_COMPACT : 0) | (int32_t)(max_arcs << NFST_BATCH_MAX_ARCS_SHIFT);
+  *total = t;
+  return NFST_OK;
+}
+
+extern "C" int nfst_concat_packed(const nfst_batch *parts, int32_t n_parts, const nfst_batch *out, int32_t n_threads) {
+  if (!parts || n_parts <= 0 || !out) return NFST_ERR_ARG;
+  nfst_batch want{};
+  int rc = nfst_concat_sizes(parts, n_parts, &want);
+  if (rc) return rc;
+  if (want.n_lattices != out->n_lattices || want.total_rows != out->total_rows || want.total_arcs != out->total_arcs ||
+      want.fwd_words != out->fwd_words || want.bwd_words != out->bwd_words || want.fwd_slots != out->fwd_slots ||
+      want.bwd_slots != out->bwd_slots || want.vocab != out->vocab || want.weighted != out->weighted)
+    return NFST_ERR_ARG;
+  if (!out->meta || !out->row_ptr || !out->fwd_stream || !out->bwd_stream || !out->arc_sd || !out->arc_l16) return NFST_ERR_ARG;
+  if (out->total_arcs > 0 && (!out->arc_src || !out->arc_dst || !out->arc_label || (out->weighted && !out->arc_w))) return NFST_ERR_ARG;
+  if ((out->fwd_slots > 0 && !out->fwd_perm) || (out->bwd_slots > 0 && !out->bwd_perm)) return NFST_ERR_ARG;
+  struct Off { int64_t lat, rows, arcs, fw, bw, fs, bs; };
+  std::vector<Off> off((size_t)n_parts);
+  Off o{0, 0, 0, 0, 0, 0, 0};
+  const int64_t slack = 512;
+  for (int i = 0; i < n_parts; ++i) {
+    off[i] = o;
+    const nfst_batch &p = parts[i];
+    o.lat += p.n_lattices; o.rows += p.total_rows; o.arcs += p.total_arcs; o.fw += p.fwd_words - slack; o.bw += p.bwd_words - slack;
+    o.fs += p.fwd_slots; o.bs += p.bwd_slots;
+  }
+  auto W32 = [](const int32_t *p) { return const_cast<int32_t *>(p); };
+  parallel_for(n_parts, n_threads, [&](int i) {
+    const nfst_batch &p = parts[i];
+    const Off &f = off[i];
+    int32_t *meta = W32(out->meta) + (size_t)f.lat * NFST_META_WORDS;
+    std::memcpy(meta, p.meta, (size_t)p.n_lattices * NFST_META_WORDS * 4);
+    for (int b = 0; b < p.n_lattices; ++b) {
+      int32_t *m = meta + (size_t)b * NFST_META_WORDS;
+      m[NFST_META_ROW_OFF] += (int32_t)f.rows; m[NFST_META_ARC_OFF] += (int32_t)f.arcs;
+      m[NFST_META_FWD_OFF] += (int32_t)f.fw; m[NFST_META_BWD_OFF] += (int32_t)f.bw;
+      m[NFST_META_FWD_SLOT_OFF] += (int32_t)f.fs; m[NFST_META_BWD_SLOT_OFF] += (int32_t)f.bs;
+    }
+    int32_t *rp = W32(out->row_ptr) + f.rows + f.lat;
+    const int64_t nrp = p.total_rows + p.n_lattices;
+    for (int64_t k = 0; k < nrp; ++k) rp[k] = p.row_ptr[k] + (int32_t)f.arcs;
+    const size_t A = (size_t)p.total_arcs;
+    if (A) {
+      std::memcpy(W32(out->arc_src) + f.arcs, p.arc_src, A * 4);
+      std::memcpy(W32(out->arc_dst) + f.arcs, p.arc_dst, A * 4);
+      std::memcpy(W32(out->arc_label) + f.arcs, p.arc_label, A * 4);
+      if (out->weighted) std::memcpy(const_cast<float *>(out->arc_w) + f.arcs, p.arc_w, A * 4);
+      std::memcpy(const_cast<uint32_t *>(out->arc_sd) + f.arcs, p.arc_sd, A * 4);
+      std::memcpy(const_cast<uint16_t *>(out->arc_l16) + f.arcs, p.arc_l16, A * 2);
+    }
+    std::memcpy(const_cast<uint32_t *>(out->fwd_stream) + f.fw, p.fwd_stream, (size_t)(p.fwd_words - slack) * 4);
+    std::memcpy(const_cast<uint32_t *>(out->bwd_stream) + f.bw, p.bwd_stream, (size_t)(p.bwd_words - slack) * 4);
+    int32_t *fp = W32(out->fwd_perm) + f.fs, *bp = W32(out->bwd_perm) + f.bs;
+    for (int64_t k = 0; k < p.fwd_slots; ++k) fp[k] = p.fwd_perm[k] < 0 ? -1 : p.fwd_perm[k] + (int32_t)f.arcs;
+    for (int64_t k = 0; k < p.bwd_slots; ++k) bp[k] = p.bwd_perm[k] < 0 ? -1 : p.bwd_perm[k] + (int32_t)f.arcs;
+  });
+  std::memset(const_cast<uint32_t *>(out->fwd_stream) + (out->fwd_words - slack), 0, slack * 4);
+  std::memset(const_cast<uint32_t *>(out->bwd_stream) + (out->bwd_words - slack), 0, slack * 4);
+  std::memset(const_cast<uint32_t *>(out->arc_sd) + out->total_arcs, 0, 8 * 4);
+  std::memset(const_cast<uint16_t *>(out->arc_l16) + out->total_arcs, 0, 8 * 2);
+  return NFST_OK;
+}
+
 extern "C" {
 
 int nfst_pack_dense(const void *emission, int emission_is_float, const int64_t *transition,

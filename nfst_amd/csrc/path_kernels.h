@@ -1516,6 +1516,7 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step(
   if (lane == 0) {
     const bool ok = sym >= 0 && sym < V;
     symbol[n] = ok ? sym : pad;
+    if (ex.not_pad && ok && sym != pad) atomicAdd(ex.not_pad, 1);
     logq[n] = ok ? xs[sym] - lz : kNegInf;
     if (logz) logz[n] = lz;
     next_state[n] = (ok && nx[sym] >= 0) ? nx[sym] : 0;  // like nfst_step: 0 where the table has no arc
@@ -1554,15 +1555,25 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_proposal_step_bwd(
     const int32_t *rp = lat.row_ptr + m.row_off + b;
     const int64_t s = vstate[n];
     // marks with an arc out of the value state add to that arc's destination row; every other legal
-    // mark read row 0 in the forward pass
-    float to_row0 = 0.0f;
-    for (int v = lane; v < V; v += 64) to_row0 += grad_of(v);
+    // mark read row 0 in the forward pass.  Row 0 gets the sum over exactly those marks (a bit set per mark with
+    // an arc, in LDS): "sum of all minus sum over the arcs" left a float32 rounding residue -- nondeterministic noise
+    // on row 0 of every lattice -- where the true value is zero (value_state = the masks' state: every legal mark
+    // has an arc).
+    __shared__ uint32_t has_arc[kStepWaves][(kStepMaxVocab + 31) / 32];
+    uint32_t *bits = has_arc[wave];
+    for (int w = lane; w < (V + 31) / 32; w += 64) bits[w] = 0u;
+    __builtin_amdgcn_wave_barrier();  // (one wave per walker: its LDS accesses execute in order)
     if (s >= 0 && s < m.n_rows)
       for (int a = rp[s] + lane; a < rp[s + 1]; a += 64) {
-        const float gv = grad_of(lat.arc_label[a]);
+        const int l = lat.arc_label[a];
+        const float gv = grad_of(l);
         if (gv != 0.0f) atomicAdd(grad_values + m.row_off + lat.arc_dst[a], gv);
-        to_row0 -= gv;
+        atomicOr(&bits[l >> 5], 1u << (l & 31));
       }
+    __builtin_amdgcn_wave_barrier();
+    float to_row0 = 0.0f;
+    for (int v = lane; v < V; v += 64)
+      if (!((bits[v >> 5] >> (v & 31)) & 1u)) to_row0 += grad_of(v);
     to_row0 = wave_sum(to_row0);
     if (lane == 0 && to_row0 != 0.0f) atomicAdd(grad_values + m.row_off, to_row0);
   }

@@ -140,102 +140,141 @@ class LatticeBatch:
         n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lattices)
         return cls.from_arcs(n_rows, arc_off, src, label, dst, lattices[0].vocab, arc_w=w, device=device, **pack_opts)
 
+    _DTYPES = {"meta": torch.int32, "row_ptr": torch.int32, "arc_src": torch.int32, "arc_dst": torch.int32, "arc_label": torch.int32,
+               "arc_w": torch.float32, "fwd_stream": torch.int32, "bwd_stream": torch.int32, "fwd_perm": torch.int32,
+               "bwd_perm": torch.int32, "arc_sd": torch.int32, "arc_l16": torch.int16}
+
     @classmethod
-    def concat(cls, batches: Sequence["LatticeBatch"], device=None) -> "LatticeBatch":
+    def _sizes(cls, h: dict) -> dict:
+        """number of elements of every array of a batch with header ``h``"""
+        B, A = h["n_lattices"], h["total_arcs"]
+        n = {"meta": B * _lib.META_WORDS, "row_ptr": h["total_rows"] + B, "arc_src": A, "arc_dst": A, "arc_label": A,
+             "fwd_stream": h["fwd_words"], "bwd_stream": h["bwd_words"], "fwd_perm": h["fwd_slots"], "bwd_perm": h["bwd_slots"],
+             "arc_sd": A + 8, "arc_l16": A + 8}
+        if h["weighted"]:
+            n["arc_w"] = A
+        return n
+
+    @classmethod
+    def concat(cls, batches: Sequence["LatticeBatch"], device=None, arena: "Optional[HostArena]" = None,
+               n_threads: int = 0) -> "LatticeBatch":
         """One batch from already packed ones, without running the packer again: pack every
         example once (in a DataLoader worker, or cache it next to the ``.npz``) and build the
-        step's batch by concatenation -- a few tensor copies and offset fix-ups.
-        The parts must agree in vocabulary and in being weighted or not."""
+        step's batch by concatenation -- ``nfst_concat_packed``: memcpy + offset fix-ups in C, threads over
+        the parts (the reference's collate pads and stacks the dense tables,
+        util/dataset_reader.py:175-186).  The parts must agree in vocabulary and in being weighted;
+        the result is bit-identical to packing the lattices as one batch.  ``arena``: write into the
+        grow-only page-locked buffers of a ``HostArena`` (valid until the arena is used again)."""
         batches = list(batches)
         if not batches:
             raise ValueError("nothing to concatenate")
-        h0 = batches[0]._h
-        if any(b._h["vocab"] != h0["vocab"] or b._h["weighted"] != h0["weighted"] for b in batches):
-            raise ValueError("batches differ in vocabulary or in being weighted")
-        SLACK = 512  # words of slack at the end of each tile stream (pack.cpp, finish())
         cpu = [b if b.device.type == "cpu" else b.to("cpu") for b in batches]
-        rows = arcs = fw = bw = fs = bs = 0
-        metas, parts = [], {k: [] for k in cls._FIELDS if k != "meta"}
-        for b in cpu:
-            h, t = b._h, b._t
-            m = b.meta_host.copy()
-            m[:, _lib.META_ROW_OFF] += rows
-            m[:, _lib.META_ARC_OFF] += arcs
-            m[:, _lib.META_FWD_OFF] += fw
-            m[:, _lib.META_BWD_OFF] += bw
-            m[:, _lib.META_FWD_SLOT_OFF] += fs
-            m[:, _lib.META_BWD_SLOT_OFF] += bs
-            metas.append(m)
-            A = h["total_arcs"]
-            parts["row_ptr"].append(t["row_ptr"] + arcs)  # global arc ids
-            for k in ("arc_src", "arc_dst", "arc_label"):
-                parts[k].append(t[k])
-            if h["weighted"]:
-                parts["arc_w"].append(t["arc_w"])
-            parts["arc_sd"].append(t["arc_sd"][:A])
-            parts["arc_l16"].append(t["arc_l16"][:A])
-            parts["fwd_stream"].append(t["fwd_stream"][: h["fwd_words"] - SLACK])
-            parts["bwd_stream"].append(t["bwd_stream"][: h["bwd_words"] - SLACK])
-            for k in ("fwd_perm", "bwd_perm"):  # slot -> global arc id, -1 = empty slot
-                p = t[k]
-                parts[k].append(torch.where(p >= 0, p + arcs, p))
-            rows += h["total_rows"]; arcs += A
-            fw += h["fwd_words"] - SLACK; bw += h["bwd_words"] - SLACK
-            fs += h["fwd_slots"]; bs += h["bwd_slots"]
-        if max(arcs, fw, bw, fs, bs, rows) > 0x7FFFF000:
-            raise _lib.NfstError(-6, "nfst_amd.LatticeBatch.concat", -1)
-        tensors = {"meta": torch.from_numpy(np.ascontiguousarray(np.concatenate(metas)).reshape(-1).astype(np.int32))}
-        for k, v in parts.items():
-            if k == "arc_w" and not h0["weighted"]:
-                tensors[k] = None
-                continue
-            x = torch.cat(v)
-            if k in ("fwd_stream", "bwd_stream"):
-                x = torch.cat([x, torch.zeros(SLACK, dtype=x.dtype)])
-            elif k in ("arc_sd", "arc_l16"):
-                x = torch.cat([x, torch.zeros(8, dtype=x.dtype)])
-            tensors[k] = x.contiguous()
-        header = dict(h0)
-        header.update(reserved0=min(b._h["reserved0"] & 1 for b in cpu)  # all-compact only if every part is
-                      | (max(b._h["reserved0"] >> 8 for b in cpu) << 8),  # (the largest arc count of one lattice)
-                      n_lattices=sum(b._h["n_lattices"] for b in cpu), max_rows=max(b._h["max_rows"] for b in cpu),
-                      max_tiles=max(b._h["max_tiles"] for b in cpu), total_rows=rows, total_arcs=arcs,
-                      total_dp_arcs=sum(b._h["total_dp_arcs"] for b in cpu), fwd_words=fw + SLACK, bwd_words=bw + SLACK,
-                      fwd_slots=fs, bwd_slots=bs)
+        parts = (_lib.Batch * len(cpu))(*[b.c_struct() for b in cpu])
+        total = _lib.Batch()
+        rc = lib.nfst_concat_sizes(parts, len(cpu), C.byref(total))
+        if rc == -1:
+            raise ValueError("batches differ in vocabulary or in being weighted")
+        check(rc, "nfst_concat_sizes")
+        header = {k: int(getattr(total, k)) for k in cls._HEADER}
+        sizes = cls._sizes(header)
+        if arena is not None:
+            tensors = arena.take(sizes, cls._DTYPES)
+        else:
+            tensors = {k: torch.empty(n, dtype=cls._DTYPES[k]) for k, n in sizes.items()}
+        tensors.setdefault("arc_w", None)
+        for k in cls._FIELDS:
+            t = tensors[k]
+            setattr(total, k, None if t is None or t.numel() == 0 else t.data_ptr())
+        check(lib.nfst_concat_packed(parts, len(cpu), C.byref(total), int(n_threads)), "nfst_concat_packed")
         out = cls(header, tensors)
         return out.to(device) if device is not None else out
 
+    def validate(self) -> None:
+        """``nfst_validate_batch``: every offset, count, state / label / arc id that a kernel turns into an
+        address without looking is inside the batch's arrays (host copy; O(words of the batch)).  Raises
+        ``NfstError``.  ``load`` calls it: a truncated, stale or damaged sidecar is refused on the host
+        instead of faulting on the GPU."""
+        b = self if self.device.type == "cpu" else self.to("cpu")
+        bad = C.c_int32(-1)
+        check(lib.nfst_validate_batch(C.byref(b.c_struct()), C.byref(bad)), "nfst_validate_batch", bad.value)
+
     # ---------------------------------------------------------------- sidecar files
-    _MAGIC = "nfst-packed"
+    # One flat file: [magic][abi, n header words, n arrays, reserved][header][per array: present, item size, elements,
+    # byte offset, CRC-32C][arrays, 64-byte aligned].  Read back through a private memory map: no decompression, no
+    # copy until the arrays are gathered into a step's batch (``concat`` into a page-locked arena).
+    _MAGIC = b"NFSTPK1\0"
 
     def save(self, fname: str) -> None:
-        """Write the packed arrays next to the example's ``.npz`` (an uncompressed ``.npz`` of
-        plain arrays): the packer then runs once per example, offline or in a DataLoader worker,
-        and a step's batch is ``concat`` of loaded sidecars."""
-        arrs = {k: v.detach().cpu().numpy() for k, v in self._t.items() if v is not None}
-        header = np.array([self._h[k] for k in self._HEADER], dtype=np.int64)
-        np.savez(fname, magic=np.array(self._MAGIC), abi=np.int64(lib.nfst_abi_version()), header=header, **arrs)
+        """Write the packed arrays next to the example's ``.npz``: the packer then runs once per example,
+        offline or in a DataLoader worker, and a step's batch is ``concat`` of loaded sidecars.
+        Every array carries a CRC-32C that ``load`` verifies."""
+        arrs = {k: (None if v is None else np.ascontiguousarray(v.detach().cpu().numpy())) for k, v in self._t.items()}
+        head = np.zeros(4 + len(self._HEADER) + 5 * len(self._FIELDS), dtype=np.int64)
+        head[0:4] = (lib.nfst_abi_version(), len(self._HEADER), len(self._FIELDS), 0)
+        head[4:4 + len(self._HEADER)] = [self._h[k] for k in self._HEADER]
+        pos = (len(self._MAGIC) + head.nbytes + 63) & ~63
+        for i, k in enumerate(self._FIELDS):
+            a = arrs[k]
+            e = 4 + len(self._HEADER) + 5 * i
+            if a is None:
+                continue
+            crc = lib.nfst_crc32c(a.ctypes.data, a.nbytes, 0) if a.nbytes else 0
+            head[e:e + 5] = (1, a.itemsize, a.size, pos, crc)
+            pos = (pos + a.nbytes + 63) & ~63
+        with open(fname, "wb") as f:
+            f.write(self._MAGIC)
+            f.write(head.tobytes())
+            for i, k in enumerate(self._FIELDS):
+                e = 4 + len(self._HEADER) + 5 * i
+                if head[e]:
+                    f.seek(int(head[e + 3]))
+                    f.write(arrs[k].tobytes())
+            f.truncate(pos)
 
     @classmethod
-    def load(cls, fname: str, device=None) -> "LatticeBatch":
-        with np.load(fname, allow_pickle=False) as l:
-            if "magic" not in l.files or str(l["magic"]) != cls._MAGIC:
-                raise ValueError(f"{fname} is not a packed lattice file")
-            if int(l["abi"]) != lib.nfst_abi_version():
-                raise ValueError(f"{fname} was packed for ABI {int(l['abi'])}, the library is ABI "
-                                 f"{lib.nfst_abi_version()}: pack it again")
-            header = {k: int(v) for k, v in zip(cls._HEADER, l["header"])}
-            tensors = {k: (torch.from_numpy(l[k]) if k in l.files else None) for k in cls._FIELDS}
-        B, A = header["n_lattices"], header["total_arcs"]
-        want = {"meta": B * _lib.META_WORDS, "row_ptr": header["total_rows"] + B, "arc_src": A, "arc_dst": A,
-                "arc_label": A, "fwd_stream": header["fwd_words"], "bwd_stream": header["bwd_words"],
-                "fwd_perm": header["fwd_slots"], "bwd_perm": header["bwd_slots"], "arc_sd": A + 8, "arc_l16": A + 8}
-        if header["weighted"]:
-            want["arc_w"] = A
-        for k, n in want.items():
-            if tensors[k] is None or tensors[k].numel() != n:
+    def load(cls, fname: str, device=None, verify: bool = True, validate: bool = True) -> "LatticeBatch":
+        """Read a sidecar written by ``save`` (memory-mapped, copy-on-write).  ``verify`` (default): the CRC-32C of
+        every array; ``validate`` (default): ``nfst_validate_batch`` -- a truncated, stale or damaged file raises
+        ``ValueError`` here and never reaches a kernel.  Both off (header and size checks only) is for files this
+        process wrote itself moments ago."""
+        try:
+            raw = np.memmap(fname, dtype=np.uint8, mode="c").view(np.ndarray)  # (plain ndarray views: memmap's own slicing is slow)
+        except (ValueError, OSError) as e:
+            raise ValueError(f"{fname} is not a packed lattice file ({e})")
+        nm = len(cls._MAGIC)
+        fixed = nm + 8 * (4 + len(cls._HEADER) + 5 * len(cls._FIELDS))
+        if raw.size < fixed or bytes(raw[:nm]) != cls._MAGIC:
+            raise ValueError(f"{fname} is not a packed lattice file")
+        head = raw[nm:fixed].view(np.int64)
+        if int(head[0]) != lib.nfst_abi_version():
+            raise ValueError(f"{fname} was packed for ABI {int(head[0])}, the library is ABI {lib.nfst_abi_version()}: pack it again")
+        if int(head[1]) != len(cls._HEADER) or int(head[2]) != len(cls._FIELDS):
+            raise ValueError(f"{fname}: unknown layout")
+        header = {k: int(v) for k, v in zip(cls._HEADER, head[4:4 + len(cls._HEADER)])}
+        if min(header.values()) < 0 or header["n_lattices"] <= 0:
+            raise ValueError(f"{fname}: bad header")
+        want = cls._sizes(header)
+        tensors = {}
+        for i, k in enumerate(cls._FIELDS):
+            present, item, n, off, crc = (int(x) for x in head[4 + len(cls._HEADER) + 5 * i:][:5])
+            if not present:
+                if k in want:
+                    raise ValueError(f"{fname}: array {k} is missing")
+                tensors[k] = None
+                continue
+            dt = cls._DTYPES[k]
+            if k not in want or n != want[k] or item != torch.empty(0, dtype=dt).element_size() or off < fixed or off % 64 or off + n * item > raw.size:
                 raise ValueError(f"{fname}: array {k} does not match the header")
+            a = raw[off:off + n * item]
+            if verify and n and lib.nfst_crc32c(a.ctypes.data, a.nbytes, 0) != (crc & 0xFFFFFFFF):
+                raise ValueError(f"{fname}: checksum of array {k} does not match (damaged or truncated file)")
+            tensors[k] = torch.from_numpy(a.view({4: np.int32, 2: np.int16}[item] if dt != torch.float32 else np.float32))
         out = cls(header, tensors)
+        if validate:
+            try:
+                out.validate()
+            except _lib.NfstError as e:
+                raise ValueError(f"{fname}: {e}")
         return out.to(device) if device is not None else out
 
     # ---------------------------------------------------------------- placement
@@ -335,3 +374,25 @@ class LatticeBatch:
         if mode == "backward":
             return 8 * arcs + 8 * states
         return 32 * arcs + 24 * states
+
+
+
+class HostArena:
+    """Grow-only host buffers, one per array of a packed batch, page-locked once (``pin=True``) and reused for every
+    batch staged through them: ``concat(..., arena=...)`` gathers a step's batch straight into page-locked memory, and
+    ``to(device, non_blocking=True)`` from there runs at the PCIe rate.  (Pinning per batch -- what
+    ``tensor.pin_memory()`` does -- costs more than the copy itself: 0.47 GB/s measured in round 2.)  A batch taken
+    from an arena is valid until the arena is used again."""
+
+    def __init__(self, pin: bool = True, slack: float = 1.25):
+        self.pin, self.slack, self.buf = bool(pin) and torch.cuda.is_available(), slack, {}
+
+    def take(self, sizes: dict, dtypes: dict) -> dict:
+        out = {}
+        for k, n in sizes.items():
+            b = self.buf.get(k)
+            if b is None or b.numel() < n:
+                b = torch.empty(max(int(n * self.slack), 64), dtype=dtypes[k], pin_memory=self.pin)
+                self.buf[k] = b
+            out[k] = b[:n]
+        return out

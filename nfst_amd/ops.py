@@ -299,13 +299,17 @@ class _ProposalStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lat, scores, values, cfg):
-        (state, inp, pad, bos, eos, has_to_end, temperature, uniforms, forced, extras, vstate, k) = cfg
+        (state, inp, pad, bos, eos, has_to_end, temperature, uniforms, forced, extras, vstate, k, out) = cfg
         N, dev = state.shape[0], lat.device
-        need = scores.requires_grad or (values is not None and values.requires_grad)
-        sym = torch.empty(N, dtype=torch.int64, device=dev)
-        nxt = torch.empty(N, dtype=torch.int64, device=dev)
-        logq = torch.empty(N, dtype=torch.float32, device=dev)
-        logz = torch.empty(N, dtype=torch.float32, device=dev)
+        # (False under torch.no_grad(): a sampling loop with trainable proposal parameters then writes no [N, V] logits)
+        need = ctx.needs_input_grad[1] or (values is not None and ctx.needs_input_grad[2])
+        if out is not None:
+            sym, logq, logz, nxt = out
+        else:
+            sym = torch.empty(N, dtype=torch.int64, device=dev)
+            nxt = torch.empty(N, dtype=torch.int64, device=dev)
+            logq = torch.empty(N, dtype=torch.float32, device=dev)
+            logz = torch.empty(N, dtype=torch.float32, device=dev)
         logits = torch.empty(N, lat.vocab, dtype=torch.float32, device=dev) if need else None
         check(lib.nfst_proposal_step(C.byref(lat.c_struct()), _ptr(state), _ptr(inp), _ptr(scores), _ptr(values), int(pad),
                                      int(bos), int(eos), int(bool(has_to_end)), float(temperature), _ptr(uniforms), _ptr(forced),
@@ -337,7 +341,7 @@ def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, 
                   eos: int = 2, has_to_end: bool = False, temperature: float = 1.0,
                   uniforms: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None,
                   value_state: Optional[torch.Tensor] = None, penalties: Optional[StepPenalties] = None,
-                  length: int = 1) -> ProposalStep:
+                  length: int = 1, out=None, not_pad: Optional[torch.Tensor] = None) -> ProposalStep:
     """One step of the reference's proposal sampler on the lattice side, fused
     (Sampler.stateful_sample, samplers.py:243-297: left_to_right_score + mask_out_invalid +
     Categorical sample / log_prob + update_fsa_state).  ``scores`` [N, V] are the proposal
@@ -346,7 +350,10 @@ def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, 
     row of the state before the previous symbol was consumed), else out of ``state``; ``penalties``
     carries the insertion / length penalty counters (scorers.py:654-677) and ``length`` is the step's
     metadata["length"]; ``uniforms`` [N] drive the inverse-CDF draw, or ``forced`` [N] gives the symbols
-    to evaluate.  ``logq`` and ``logz`` are differentiable in ``scores`` and ``values``."""
+    to evaluate.  ``logq`` and ``logz`` are differentiable in ``scores`` and ``values``.
+    ``out`` = (symbol, logq, logz, next_state) tensors of a previous call or rows of buffers allocated once per
+    sampling loop; ``not_pad``: an int32 device word (zeroed by the caller) that receives the number of walkers
+    whose symbol is not ``pad`` (zero: every walker has ended)."""
     _need_gpu(lat)
     state = _walkers(lat, state, k, "state")
     N = state.shape[0]
@@ -367,8 +374,16 @@ def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, 
     if forced is not None:
         forced = forced.to(device=dev, dtype=torch.int64).contiguous().reshape(N)
     extras = None
-    if value_state is not None or penalties is not None:
+    if not_pad is not None and (not_pad.dtype != torch.int32 or not_pad.numel() != 1 or not_pad.device != dev):
+        raise ValueError("not_pad must be one int32 word on the batch's device")
+    if out is not None:
+        want = ((torch.int64, "symbol"), (torch.float32, "logq"), (torch.float32, "logz"), (torch.int64, "next_state"))
+        if len(out) != 4 or any(o.dtype != d or o.shape != (N,) or o.device != dev or not o.is_contiguous() for o, (d, _) in zip(out, want)):
+            raise ValueError("out must be (symbol int64, logq float32, logz float32, next_state int64), each [N] on the batch's device")
+    if value_state is not None or penalties is not None or not_pad is not None:
         extras = _lib.StepExtras()
+        if not_pad is not None:
+            extras.not_pad = not_pad.data_ptr()
         if value_state is not None:
             value_state = _walkers(lat, value_state, k, "value_state")
             extras.value_state = value_state.data_ptr()
@@ -382,7 +397,7 @@ def proposal_step(lat: LatticeBatch, state: torch.Tensor, scores: torch.Tensor, 
             extras.insert_penalty, extras.length_threshold = penalties.insert_penalty, penalties.length_threshold
             extras.length_penalty, extras.length = penalties.length_penalty, int(length)
     vstate = value_state if value_state is not None else state
-    cfg = (state, inp, pad, bos, eos, has_to_end, temperature, uniforms, forced, extras, vstate, k)
+    cfg = (state, inp, pad, bos, eos, has_to_end, temperature, uniforms, forced, extras, vstate, k, out)
     return ProposalStep(*_ProposalStep.apply(lat, scores, values, cfg))
 
 

@@ -128,27 +128,46 @@ class ProposalSampler(Sampler):
         pen = None
         if self.penalties is not None:
             pen = ops.StepPenalties(batch_size, lat.vocab, dev, **self.penalties)
-        log_q = torch.zeros(batch_size, dtype=torch.float32, device=dev)
-        zs = torch.zeros(batch_size, dtype=torch.float32, device=dev)
-        prefixes = []
-        hard_cut = True
-        for timestep in range(m.max_length + 1):  # + 1 for the additional padding at the end
-            if evaluate_only and timestep >= padded.shape[1]:
-                break
+        # Outputs of all steps live in buffers allocated once; "has every walker ended" is a device word per step that
+        # the kernel counts into, read back every CHECK steps: one host-device synchronisation per CHECK steps instead
+        # of one per step (the reference tests all_reached_eos at every step, samplers.py:288-290).  Steps that ran
+        # past the first all-pad step are dropped again, hx included: results are those of the step-by-step loop.
+        CHECK = 8
+        T = (m.max_length + 1) if not evaluate_only else min(m.max_length + 1, padded.shape[1])
+        sym_all = torch.empty((T, batch_size), dtype=torch.int64, device=dev)
+        nxt_all = torch.empty((T, batch_size), dtype=torch.int64, device=dev)
+        logq_all = torch.empty((T, batch_size), dtype=torch.float32, device=dev)
+        logz_all = torch.empty((T, batch_size), dtype=torch.float32, device=dev)
+        not_pad = torch.zeros(T, dtype=torch.int32, device=dev)
+        logqs, logzs, hxs = [], [], []
+        n_steps, hard_cut = 0, True
+        for timestep in range(T):
             hx, logits = self.score_fn(hx, inp)
             r = ops.proposal_step(lat, state, logits, k=m.k, inp=inp, values=values, pad=m.__pad__, bos=m.__bos__,
                                   eos=m.__eos__, has_to_end=(timestep + 1) > m.max_length, temperature=temperature,
                                   uniforms=None if (evaluate_only or uniforms is None) else uniforms[timestep],
                                   forced=padded[:, timestep] if evaluate_only else None,
                                   value_state=prev_state if (values is not None and self.beta_from_previous_state) else None,
-                                  penalties=pen, length=timestep + 1)
-            log_q = log_q + r.logq
-            zs = zs + r.logz
-            prefixes.append(r.symbol)
+                                  penalties=pen, length=timestep + 1,
+                                  out=(sym_all[timestep], logq_all[timestep], logz_all[timestep], nxt_all[timestep]),
+                                  not_pad=not_pad[timestep:timestep + 1])
+            logqs.append(r.logq)
+            logzs.append(r.logz)
+            hxs.append(hx)
             prev_state, state, inp = state, r.next_state, r.symbol
-            if self.all_reached_eos(r.symbol):
-                hard_cut = False
-                break
+            n_steps = timestep + 1
+            if n_steps % CHECK == 0 or n_steps == T:
+                first = n_steps - (CHECK if n_steps % CHECK == 0 else n_steps % CHECK)
+                ended = (not_pad[first:n_steps] == 0).nonzero()
+                if ended.numel():
+                    n_steps = first + int(ended[0]) + 1  # the first step at which every symbol was pad
+                    hard_cut = False
+                    break
+        hx = hxs[n_steps - 1] if n_steps else hx
+        zero = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        log_q = torch.stack(logqs[:n_steps]).sum(dim=0) if n_steps else zero
+        zs = torch.stack(logzs[:n_steps]).sum(dim=0) if n_steps else zero
+        prefixes = [sym_all[t] for t in range(n_steps)]
         if hard_cut and not evaluate_only:
             raise Exception("a sample did not end within max_length + 1 steps")  # the reference raises here too (samplers.py:299-302)
         if evaluate_only:

@@ -121,7 +121,10 @@ class NeuralBetaScorer(LatticeScorer):
         self.beta_bias = torch.nn.Parameter(torch.zeros(hid_dim))
 
     def compute_beta_hat(self):
-        """``(log beta [B*k, S+1], beta_hat [B*k, S+1, H])``."""
+        """``(log beta [B*k, S+1], beta_hat [B*k, S+1, H])``.  Differentiable in the five parameters
+        (``tune_proposal`` trains them through it): under autograd the call keeps the forward workspace for the
+        backward pass -- 2 B max_rows (H + 1) floats, 1.1 GB at H = 256 on the BASELINE batch.  A caller that only
+        samples wraps the call in ``torch.no_grad()`` and nothing is kept."""
         lat = self._lat()
         r = ops.backward_neural(lat, self.embeddings.weight, self.Wx, self.Wh, self.W, self.beta_bias)
         return (lat.rows_view(r.log_beta).repeat_interleave(self.k, dim=0),

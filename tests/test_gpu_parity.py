@@ -999,7 +999,7 @@ def test_beta_neural_matches_reference_fixture(dev, golden_dir, name):
     assert np.max(np.abs(r.beta_hat.cpu().numpy() - bhat)) <= 2e-5
 
 
-@pytest.mark.parametrize("H", [5, 8, 24, 32, 64, 100, 256, 512])
+@pytest.mark.parametrize("H", [5, 8, 24, 32, 64, 100, 128, 192, 256, 320, 512])
 def test_beta_neural_against_oracle(dev, H):
     """Mixed batch (sizes, a 200-way fan-out and fan-in, weighted tables) under every packing the
     host can choose: carry pieces and partial groups merge (beta, beta_hat) by weight."""
@@ -1099,7 +1099,7 @@ def test_beta_neural_grad_matches_reference_differences(dev, golden_dir, name):
         assert rec("neural_grad_rel", _rel(got[k].reshape(-1), ref[k].reshape(-1))) <= 1e-4, k
 
 
-@pytest.mark.parametrize("H", [5, 8, 16, 24, 32, 64, 100, 256, 512])
+@pytest.mark.parametrize("H", [5, 8, 16, 24, 32, 64, 100, 128, 192, 256, 384, 512])
 def test_beta_neural_grad_against_autograd(dev, H):
     """Mixed batch (weighted tables; a near-sequential, a layered and a wide lattice) under several
     packings, with gradients entering through log beta AND beta_hat: float64 autograd over the

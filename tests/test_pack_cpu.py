@@ -210,14 +210,82 @@ def test_packed_sidecar_round_trip(tmp_path):
     with pytest.raises(ValueError):
         LatticeBatch.load(names[0])
     side = io.packed_sidecar(names[0])
-    with np.load(side) as l:
-        d = {k: l[k] for k in l.files}
-    d["abi"] = np.int64(1)
-    np.savez(side, **d)
+    raw = bytearray(open(side, "rb").read())
+    stale = bytearray(raw)
+    stale[8:16] = np.int64(1).tobytes()  # the ABI word
+    open(side, "wb").write(stale)
     with pytest.raises(ValueError, match="ABI"):
         LatticeBatch.load(side)
     os.utime(side, (os.path.getmtime(names[0]) + 10,) * 2)
     assert io.load_packed(names[0])._h == first[0]._h  # rebuilt
+
+
+def test_sidecar_content_checks(tmp_path):
+    """A damaged, truncated or inconsistent sidecar never reaches a kernel: every array carries a CRC-32C
+    (``nfst_crc32c``) that ``load`` verifies, and ``nfst_validate_batch`` checks every offset, count and id the
+    kernels turn into addresses -- with the checksums switched off too."""
+    from nfst_amd import _lib
+    lats = [synth.layered_lattice(50 + i, n_states=60 + 20 * i, avg_degree=4.0, vocab=40, width=3, span=2, weighted=(i == 1)) for i in range(2)]
+    for l in lats:
+        lat = LatticeBatch.from_synth([l])
+        lat.validate()
+        f = str(tmp_path / "x.nfstpk")
+        lat.save(f)
+        back = LatticeBatch.load(f)
+        assert back._h == lat._h
+        for k in LatticeBatch._FIELDS:
+            x, y = getattr(lat, k), getattr(back, k)
+            assert (x is None and y is None) or (x.dtype == y.dtype and torch.equal(x, y)), k
+        raw = bytearray(open(f, "rb").read())
+        # one flipped byte in the middle of the arrays: the checksum catches it
+        bad = bytearray(raw)
+        bad[len(bad) // 2] ^= 0x40
+        open(f, "wb").write(bad)
+        with pytest.raises(ValueError, match="checksum"):
+            LatticeBatch.load(f)
+        # truncated file
+        open(f, "wb").write(raw[: len(raw) - 4096])
+        with pytest.raises(ValueError):
+            LatticeBatch.load(f)
+        open(f, "wb").write(raw)
+        # structural damage with the checksums off: a tile record that names a state beyond max_rows, a slot -> arc
+        # map entry beyond the lattice's arcs, a meta record whose program runs past the stream
+        for field, poison in (("bwd_stream", None), ("fwd_perm", 1 << 28), ("meta", None), ("arc_dst", 1 << 20), ("row_ptr", -5)):
+            t = {k: (None if v is None else v.clone()) for k, v in lat._t.items()}
+            if field == "bwd_stream":
+                t[field][1] = t[field][1] | 0x1fff  # first record of the first lane: state 8191
+            elif field == "meta":
+                t[field][_lib.META_BWD_TILES] += 100000
+            else:
+                t[field][3] = poison
+            broken = LatticeBatch(lat._h, t)
+            with pytest.raises(_lib.NfstError):
+                broken.validate()
+            broken.save(f)
+            with pytest.raises(ValueError):
+                LatticeBatch.load(f, verify=False)
+    # the checksum itself: CRC-32C of "123456789" is 0xE3069283; chaining through the seed
+    msg = np.frombuffer(b"123456789", dtype=np.uint8)
+    assert _lib.lib.nfst_crc32c(msg.ctypes.data, 9, 0) == 0xE3069283
+    part = _lib.lib.nfst_crc32c(msg.ctypes.data, 4, 0)
+    assert _lib.lib.nfst_crc32c(msg[4:].ctypes.data, 5, part) == 0xE3069283
+
+
+def test_concat_into_arena_and_threads():
+    """``concat`` into the grow-only buffers of a ``HostArena`` (reused from batch to batch) and with several host
+    threads gives the arrays of the plain concatenation."""
+    from nfst_amd.lattice import HostArena
+    lats = [synth.layered_lattice(70 + i, n_states=40 + 31 * i, avg_degree=5.0, vocab=64, width=1 + i % 4, span=3) for i in range(7)]
+    parts = [LatticeBatch.from_synth([l]) for l in lats]
+    arena = HostArena(pin=False)
+    for sel in (parts, parts[:3], parts[2:]):  # the arena's buffers are reused and outgrown
+        ref = LatticeBatch.concat(sel, n_threads=1)
+        got = LatticeBatch.concat(sel, arena=arena, n_threads=4)
+        assert got._h == ref._h
+        for k in LatticeBatch._FIELDS:
+            x, y = getattr(ref, k), getattr(got, k)
+            assert (x is None and y is None) or torch.equal(x, y), k
+        got.validate()
 
 
 def test_graft_entry_build_runs():
