@@ -220,6 +220,55 @@ uint32_t nfst_crc32c(const void *data, int64_t n_bytes, uint32_t seed);
 int nfst_concat_sizes(const nfst_batch *parts, int32_t n_parts, nfst_batch *total);
 int nfst_concat_packed(const nfst_batch *parts, int32_t n_parts, const nfst_batch *out, int32_t n_threads);
 
+/*
+ * The packer on the device (SURVEY.md section 2 "K1", section 7 step 4).  The reference's trainer hands set_masks
+ * tables that already live on the GPU (modules/lightning.py:417 -> scorers.py:877-885); these entry points pack them
+ * there, and pack compact arc lists (12 bytes per arc) uploaded by a loader.  Output: the arrays of an nfst_batch in
+ * device memory, BIT-IDENTICAL to nfst_pack_dense / nfst_pack_arcs on the same lattices.  Supported: vocab + 2 <= 2048
+ * (compact tiles, four slots per lane), nfst_pack_opts.group_mode; slots_per_lane must be 0 or 4.  A lattice beyond
+ * the device packer's limits (more than 16384 reachable states or pieces of one sweep direction) gets NFST_ERR_LIMIT in
+ * its status word: pack that batch on the host.
+ *
+ * Dense tables -> arc lists, two launches around one small read-back:
+ *   nfst_dense_to_arcs_count  reach [B, n_rows] bytes, row_cnt [B, n_rows], counts [B] = arcs of the rows reachable
+ *                             from state 0 (collate padding rows never become arcs), status [B] (NFST_ERR_INDEX)
+ *   (host: arc_off = prefix sums of counts; allocate src / label / dst (/ arc_w) of arc_off[B] entries)
+ *   nfst_dense_to_arcs_write  the arcs of lattice b at arc_off[b] in (state, label) order
+ * Arc lists -> packed batch, two launches around one small read-back:
+ *   nfst_pack_device_plan     meta [B, 16] counts (rows, arcs, tiles, sink, depth, formats), status [B], scratch_rows [B]
+ *   nfst_pack_device_layout   (host) offsets into *meta, sizes and flags into *header: allocate the arrays, store their
+ *                             device addresses in the header, upload meta (it is the batch's meta array)
+ *   nfst_pack_device_emit     writes every array of the batch
+ * ws: device workspace of nfst_pack_device_ws_bytes() bytes, contents irrelevant, may be reused at once.
+ */
+typedef struct nfst_arcs_device {
+  const int32_t *n_rows;   /* [B] device */
+  const int64_t *row_off;  /* [B + 1] device: prefix sums of n_rows */
+  const int64_t *arc_off;  /* [B + 1] device */
+  const int32_t *src;      /* [total_arcs] device, sorted by (src, label) inside a lattice */
+  const int32_t *label;
+  const int32_t *dst;
+  const float *arc_w;      /* or NULL */
+  int64_t total_rows;      /* = row_off[B] */
+  int64_t total_arcs;      /* = arc_off[B] */
+  int32_t n_lattices;
+  int32_t vocab;
+} nfst_arcs_device;
+
+int nfst_dense_to_arcs_count(const void *emission, int emission_is_float, const int64_t *transition, int32_t n_lattices,
+                             int32_t n_rows, int32_t vocab, uint8_t *reach, int32_t *row_cnt, int32_t *counts,
+                             int32_t *status, void *stream);
+int nfst_dense_to_arcs_write(const void *emission, int emission_is_float, const int64_t *transition, int32_t n_lattices,
+                             int32_t n_rows, int32_t vocab, const uint8_t *reach, const int32_t *row_cnt,
+                             const int64_t *arc_off, int32_t *src, int32_t *label, int32_t *dst, float *arc_w, void *stream);
+int64_t nfst_pack_device_ws_bytes(int32_t n_lattices, int64_t total_rows, int64_t total_arcs);
+int nfst_pack_device_plan(const nfst_arcs_device *arcs, const nfst_pack_opts *opts, void *ws, int64_t ws_bytes, int32_t *meta,
+                          int32_t *status, int32_t *scratch_rows, void *stream);
+int nfst_pack_device_layout(int32_t *meta, const int32_t *status, const int32_t *scratch_rows, int32_t n_lattices,
+                            int32_t vocab, int32_t weighted, nfst_batch *header, int32_t *err_lattice);
+int nfst_pack_device_emit(const nfst_arcs_device *arcs, const nfst_pack_opts *opts, void *ws, int64_t ws_bytes,
+                          const int32_t *meta, int32_t *status, const nfst_batch *out, void *stream);
+
 /* view of the arrays owned by a packed batch (host pointers, valid until free) */
 int nfst_packed_view(const nfst_packed *p, nfst_batch *view);
 void nfst_packed_free(nfst_packed *p);

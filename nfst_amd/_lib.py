@@ -61,6 +61,12 @@ class StepExtras(C.Structure):
                 ("not_pad", C.c_void_p)]
 
 
+class ArcsDevice(C.Structure):
+    _fields_ = [("n_rows", C.c_void_p), ("row_off", C.c_void_p), ("arc_off", C.c_void_p), ("src", C.c_void_p), ("label", C.c_void_p),
+                ("dst", C.c_void_p), ("arc_w", C.c_void_p), ("total_rows", C.c_int64), ("total_arcs", C.c_int64),
+                ("n_lattices", C.c_int32), ("vocab", C.c_int32)]
+
+
 class PackOpts(C.Structure):
     _fields_ = [("n_threads", C.c_int32), ("slots_per_lane", C.c_int32), ("group_mode", C.c_int32),
                 ("reserved1", C.c_int32)]
@@ -83,6 +89,12 @@ def _load():
         "nfst_pack_dense": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
         "nfst_pack_arcs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
         "nfst_packed_view": (C.c_int, [vp, BP]),
+        "nfst_dense_to_arcs_count": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "nfst_dense_to_arcs_write": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "nfst_pack_device_ws_bytes": (i64, [i32, i64, i64]),
+        "nfst_pack_device_plan": (C.c_int, [C.POINTER(ArcsDevice), C.POINTER(PackOpts), vp, i64, vp, vp, vp, vp]),
+        "nfst_pack_device_layout": (C.c_int, [vp, vp, vp, i32, i32, i32, BP, C.POINTER(i32)]),
+        "nfst_pack_device_emit": (C.c_int, [C.POINTER(ArcsDevice), C.POINTER(PackOpts), vp, i64, vp, vp, BP, vp]),
         "nfst_validate_batch": (C.c_int, [BP, C.POINTER(i32)]),
         "nfst_crc32c": (C.c_uint32, [vp, i64, C.c_uint32]),
         "nfst_concat_sizes": (C.c_int, [BP, i32, BP]),

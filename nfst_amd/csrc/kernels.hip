@@ -10,6 +10,7 @@
 // beta sweep (neural_kernels.h) has one dense product per state and runs it on float32 MFMA.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <cmath>
@@ -27,6 +28,7 @@ namespace {
 #include "fb_kernels.h"
 #include "path_kernels.h"
 #include "neural_kernels.h"
+#include "pack_kernels.h"
 
 // ------------------------------------------------------------------ host helpers
 int check_batch(const nfst_batch *lat) {
@@ -155,6 +157,97 @@ int nfst_tuning_set(const char *name, int value) {
   else if (n == "lds_reserve_kb") t.lds_reserve = (value > 0 && value <= 96) ? (int64_t)value * 1024 : 0;
   else return NFST_ERR_ARG;
   return NFST_OK;
+}
+
+// ---------------------------------------------------------------- the packer on the device
+int nfst_dense_to_arcs_count(const void *emission, int emission_is_float, const int64_t *transition, int32_t n_lattices,
+                             int32_t n_rows, int32_t vocab, uint8_t *reach, int32_t *row_cnt, int32_t *counts,
+                             int32_t *status, void *stream) {
+  if (!emission || !transition || !reach || !row_cnt || !counts || !status || n_lattices <= 0 || n_rows <= 0 || vocab <= 0) return NFST_ERR_ARG;
+  if (n_rows > NFST_MAX_ROWS || vocab > NFST_MAX_VOCAB) return NFST_ERR_LIMIT;
+  const int64_t lds = (int64_t)n_rows * 12;
+  int rc;
+  if (emission_is_float) {
+    if ((rc = set_lds(k_dense_reach<true>, lds))) return rc;
+    hipLaunchKernelGGL(k_dense_reach<true>, dim3(n_lattices), dim3(kPkThreads), (size_t)lds, (hipStream_t)stream, emission, transition,
+                       (int)n_rows, (int)vocab, reach, row_cnt, counts, status);
+  } else {
+    if ((rc = set_lds(k_dense_reach<false>, lds))) return rc;
+    hipLaunchKernelGGL(k_dense_reach<false>, dim3(n_lattices), dim3(kPkThreads), (size_t)lds, (hipStream_t)stream, emission, transition,
+                       (int)n_rows, (int)vocab, reach, row_cnt, counts, status);
+  }
+  return hip_status(hipGetLastError());
+}
+
+int nfst_dense_to_arcs_write(const void *emission, int emission_is_float, const int64_t *transition, int32_t n_lattices,
+                             int32_t n_rows, int32_t vocab, const uint8_t *reach, const int32_t *row_cnt,
+                             const int64_t *arc_off, int32_t *src, int32_t *label, int32_t *dst, float *arc_w, void *stream) {
+  if (!emission || !transition || !reach || !row_cnt || !arc_off || !src || !label || !dst || n_lattices <= 0 || n_rows <= 0 || vocab <= 0)
+    return NFST_ERR_ARG;
+  if (emission_is_float && !arc_w) return NFST_ERR_ARG;
+  if (n_rows > NFST_MAX_ROWS || vocab > NFST_MAX_VOCAB) return NFST_ERR_LIMIT;
+  const int64_t lds = (int64_t)n_rows * 4;
+  if (emission_is_float)
+    hipLaunchKernelGGL(k_dense_write<true>, dim3(n_lattices), dim3(kPkThreads), (size_t)lds, (hipStream_t)stream, emission, transition,
+                       (int)n_rows, (int)vocab, reach, row_cnt, arc_off, src, label, dst, arc_w);
+  else
+    hipLaunchKernelGGL(k_dense_write<false>, dim3(n_lattices), dim3(kPkThreads), (size_t)lds, (hipStream_t)stream, emission, transition,
+                       (int)n_rows, (int)vocab, reach, row_cnt, arc_off, src, label, dst, arc_w);
+  return hip_status(hipGetLastError());
+}
+
+int64_t nfst_pack_device_ws_bytes(int32_t n_lattices, int64_t total_rows, int64_t total_arcs) {
+  if (n_lattices <= 0 || total_rows < 0 || total_arcs < 0) return NFST_ERR_ARG;
+  return 4 * pk_ws_words(n_lattices, total_rows, total_arcs);
+}
+
+static int pack_device_args(const nfst_arcs_device *arcs, const nfst_pack_opts *opts, void *ws, int64_t ws_bytes, PkArgs *a) {
+  if (!arcs || !ws || arcs->n_lattices <= 0 || arcs->vocab <= 0 || !arcs->n_rows || !arcs->row_off || !arcs->arc_off) return NFST_ERR_ARG;
+  if (arcs->total_arcs > 0 && (!arcs->src || !arcs->label || !arcs->dst)) return NFST_ERR_ARG;
+  if (arcs->vocab + 2 > 2048) return NFST_ERR_LIMIT;  // compact tiles only: the host packer takes wider vocabularies
+  if (opts && ((opts->slots_per_lane != 0 && opts->slots_per_lane != 4) || opts->reserved1 == 1)) return NFST_ERR_LIMIT;
+  if (ws_bytes < 4 * pk_ws_words(arcs->n_lattices, arcs->total_rows, arcs->total_arcs) || ((uintptr_t)ws & 15)) return NFST_ERR_ARG;
+  *a = PkArgs{};
+  a->n_rows = arcs->n_rows; a->row_off = arcs->row_off; a->arc_off = arcs->arc_off;
+  a->src = arcs->src; a->label = arcs->label; a->dst = arcs->dst; a->w = arcs->arc_w;
+  a->vocab = arcs->vocab; a->group_mode = opts ? opts->group_mode : 0;
+  a->ws = (int32_t *)ws; a->total_rows = arcs->total_rows; a->total_arcs = arcs->total_arcs; a->n_lattices = arcs->n_lattices;
+  return NFST_OK;
+}
+
+int nfst_pack_device_plan(const nfst_arcs_device *arcs, const nfst_pack_opts *opts, void *ws, int64_t ws_bytes, int32_t *meta,
+                          int32_t *status, int32_t *scratch_rows, void *stream) {
+  PkArgs a;
+  int rc = pack_device_args(arcs, opts, ws, ws_bytes, &a);
+  if (rc) return rc;
+  if (!meta || !status || !scratch_rows) return NFST_ERR_ARG;
+  a.meta = meta; a.status = status; a.scratch = scratch_rows;
+  if ((rc = set_lds(k_pack_lattice<false>, kPkLdsBytes))) return rc;
+  hipLaunchKernelGGL(k_pack_lattice<false>, dim3(arcs->n_lattices), dim3(kPkThreads), (size_t)kPkLdsBytes, (hipStream_t)stream, a);
+  return hip_status(hipGetLastError());
+}
+
+int nfst_pack_device_emit(const nfst_arcs_device *arcs, const nfst_pack_opts *opts, void *ws, int64_t ws_bytes,
+                          const int32_t *meta, int32_t *status, const nfst_batch *out, void *stream) {
+  PkArgs a;
+  int rc = pack_device_args(arcs, opts, ws, ws_bytes, &a);
+  if (rc) return rc;
+  if (!meta || !status || !out || out->n_lattices != arcs->n_lattices) return NFST_ERR_ARG;
+  if ((rc = check_batch(out))) return rc;
+  if (!out->arc_sd || !out->arc_l16 || (arcs->arc_w && !out->arc_w)) return NFST_ERR_ARG;
+  if ((((uintptr_t)out->fwd_perm | (uintptr_t)out->bwd_perm) & 15)) return NFST_ERR_ARG;
+  a.meta = const_cast<int32_t *>(meta); a.status = status; a.scratch = nullptr; a.out = *out;
+  // the slack behind the streams and the 8 spare entries of the 6-byte arc arrays are part of the format: zero
+  const int64_t slack = 512;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(const_cast<uint32_t *>(out->fwd_stream) + (out->fwd_words - slack), 0, slack * 4, st) != hipSuccess ||
+      hipMemsetAsync(const_cast<uint32_t *>(out->bwd_stream) + (out->bwd_words - slack), 0, slack * 4, st) != hipSuccess ||
+      hipMemsetAsync(const_cast<uint32_t *>(out->arc_sd) + out->total_arcs, 0, 8 * 4, st) != hipSuccess ||
+      hipMemsetAsync(const_cast<uint16_t *>(out->arc_l16) + out->total_arcs, 0, 8 * 2, st) != hipSuccess)
+    return NFST_ERR_HIP;
+  if ((rc = set_lds(k_pack_lattice<true>, kPkLdsBytes))) return rc;
+  hipLaunchKernelGGL(k_pack_lattice<true>, dim3(arcs->n_lattices), dim3(kPkThreads), (size_t)kPkLdsBytes, (hipStream_t)stream, a);
+  return hip_status(hipGetLastError());
 }
 
 int64_t nfst_lds_bytes(const nfst_batch *lat) {

@@ -614,6 +614,38 @@ extern "C" int nfst_concat_packed(const nfst_batch *parts, int32_t n_parts, cons
   return NFST_OK;
 }
 
+// Offsets and header of a batch planned on the device (the counterpart of finish() above): meta holds the counts the
+// planning kernel wrote; the offsets are prefix sums in lattice order, exactly as the host packer lays the arrays out.
+extern "C" int nfst_pack_device_layout(int32_t *meta, const int32_t *status, const int32_t *scratch_rows, int32_t n_lattices,
+                                       int32_t vocab, int32_t weighted, nfst_batch *header, int32_t *err_lattice) {
+  if (!meta || !status || !scratch_rows || !header || n_lattices <= 0 || vocab <= 0) return NFST_ERR_ARG;
+  for (int b = 0; b < n_lattices; ++b)
+    if (status[b] != NFST_OK) { if (err_lattice) *err_lattice = b; return status[b]; }
+  nfst_batch h{};
+  int64_t rows = 0, arcs = 0, dp = 0, fw = 0, bw = 0, fs = 0, bs = 0, max_arcs = 0;
+  int max_rows = 0, max_tiles = 0;
+  for (int b = 0; b < n_lattices; ++b) {
+    int32_t *m = meta + (size_t)b * NFST_META_WORDS;
+    const int64_t ft = m[NFST_META_FWD_TILES], bt = m[NFST_META_BWD_TILES];
+    m[NFST_META_ROW_OFF] = (int32_t)rows; m[NFST_META_ARC_OFF] = (int32_t)arcs;
+    m[NFST_META_FWD_OFF] = (int32_t)fw; m[NFST_META_BWD_OFF] = (int32_t)bw;
+    m[NFST_META_FWD_SLOT_OFF] = (int32_t)fs; m[NFST_META_BWD_SLOT_OFF] = (int32_t)bs;
+    rows += m[NFST_META_N_ROWS]; arcs += m[NFST_META_N_ARCS]; dp += m[NFST_META_N_DP];
+    fw += ft * 256; bw += bt * 256; fs += ft * 256; bs += bt * 256;  // compact tiles: 256 words, 256 slots each
+    max_rows = std::max(max_rows, m[NFST_META_N_ROWS] + scratch_rows[b]);
+    max_tiles = std::max<int64_t>(max_tiles, std::max(ft, bt));
+    max_arcs = std::max<int64_t>(max_arcs, m[NFST_META_N_ARCS]);
+    if (arcs > 0x7fffff00ll || fw > 0x7ffff000ll || bw > 0x7ffff000ll || rows > 0x7fffff00ll) { if (err_lattice) *err_lattice = b; return NFST_ERR_LIMIT; }
+  }
+  const int64_t slack = 512;
+  h.n_lattices = n_lattices; h.vocab = vocab; h.max_rows = max_rows; h.max_tiles = max_tiles; h.weighted = weighted ? 1 : 0;
+  h.reserved0 = NFST_BATCH_ALL_COMPACT | (int32_t)(std::min<int64_t>(max_arcs, NFST_BATCH_MAX_ARCS_CAP) << NFST_BATCH_MAX_ARCS_SHIFT);
+  h.total_rows = rows; h.total_arcs = arcs; h.total_dp_arcs = dp;
+  h.fwd_words = fw + slack; h.bwd_words = bw + slack; h.fwd_slots = fs; h.bwd_slots = bs;
+  *header = h;
+  return NFST_OK;
+}
+
 extern "C" {
 
 int nfst_pack_dense(const void *emission, int emission_is_float, const int64_t *transition,

@@ -99,6 +99,14 @@ class LatticeBatch:
         (scorers.py:877-885; collated as in util/dataset_reader.py:175-186)."""
         if device is None and isinstance(transition, torch.Tensor) and transition.is_cuda:
             device = transition.device
+        if isinstance(transition, torch.Tensor) and transition.is_cuda and isinstance(emission, torch.Tensor) and emission.is_cuda:
+            # tables that already live on the GPU (the reference's trainer moves the collated batch there before
+            # set_masks, lightning.py:417) are packed there; only what the device packer does not take goes back to the host
+            try:
+                return cls.from_dense_device(emission, transition, **pack_opts).to(device)
+            except _lib.NfstError as e:
+                if e.code != -6:  # NFST_ERR_LIMIT: beyond the device packer (wide vocabulary, > 16384 states or pieces)
+                    raise
         is_float = (emission.dtype.is_floating_point if isinstance(emission, torch.Tensor)
                     else np.issubdtype(np.asarray(emission).dtype, np.floating))
         em = _host(emission, np.float32 if is_float else np.bool_)
@@ -133,6 +141,109 @@ class LatticeBatch:
                                 C.byref(opts), C.byref(handle), C.byref(bad))
         check(rc, "nfst_pack_arcs", bad.value)
         return cls._from_handle(handle, device)
+
+    # ---------------------------------------------------------------- the packer on the device
+    @classmethod
+    def from_arcs_device(cls, n_rows, arc_off, src, label, dst, vocab: int, arc_w=None, device=None, **pack_opts) -> "LatticeBatch":
+        """``from_arcs`` with the packer running on the GPU (``nfst_pack_device_plan`` / ``_emit``): arc lists sorted by
+        (src, label) -- 12 bytes per arc, what a loader uploads instead of 47-byte-per-arc packed batches or 5 MB dense
+        tables.  ``n_rows`` and ``arc_off`` are small host arrays; ``src / label / dst (/ arc_w)`` may be host arrays
+        (uploaded here) or tensors already on the device.  The result is bit-identical to ``from_arcs``.  Raises
+        ``NfstError(NFST_ERR_LIMIT)`` for what only the host packer takes (vocab + 2 > 2048, > 16384 reachable states
+        or pieces of one sweep)."""
+        n_rows = np.ascontiguousarray(_host(n_rows, np.int32))
+        arc_off = np.ascontiguousarray(_host(arc_off, np.int64))
+        B = int(n_rows.shape[0])
+        if arc_off.shape[0] != B + 1:
+            raise ValueError("inconsistent arc list shapes")
+        if device is None:
+            device = src.device if isinstance(src, torch.Tensor) and src.is_cuda else torch.device("cuda")
+        dev = torch.device(device)
+
+        def up(x, dt):
+            if isinstance(x, torch.Tensor):
+                return x.to(device=dev, dtype=dt).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int32: np.int32, torch.float32: np.float32, torch.int64: np.int64}[dt])).to(dev)
+
+        src_d, label_d, dst_d = up(src, torch.int32), up(label, torch.int32), up(dst, torch.int32)
+        w_d = None if arc_w is None else up(arc_w, torch.float32)
+        total_arcs = int(arc_off[-1])
+        if not (src_d.numel() == label_d.numel() == dst_d.numel() == total_arcs) or (w_d is not None and w_d.numel() != total_arcs):
+            raise ValueError("inconsistent arc list shapes")
+        row_off = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(n_rows, out=row_off[1:])
+        total_rows = int(row_off[-1])
+        small = torch.from_numpy(np.concatenate([row_off, arc_off, n_rows.astype(np.int64)])).to(dev)  # one upload
+        row_off_d, arc_off_d = small[:B + 1], small[B + 1:2 * B + 2]
+        n_rows_d = small[2 * B + 2:].to(torch.int32)
+        opts = cls._opts(**pack_opts)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        arcs = _lib.ArcsDevice(n_rows_d.data_ptr(), row_off_d.data_ptr(), arc_off_d.data_ptr(), src_d.data_ptr(), label_d.data_ptr(),
+                               dst_d.data_ptr(), None if w_d is None else w_d.data_ptr(), total_rows, total_arcs, B, int(vocab))
+        ws_bytes = int(lib.nfst_pack_device_ws_bytes(B, total_rows, total_arcs))
+        check(min(ws_bytes, 0), "nfst_pack_device_ws_bytes")
+        ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.int32, device=dev)
+        plan = torch.empty(B * (_lib.META_WORDS + 2), dtype=torch.int32, device=dev)  # meta | status | scratch rows
+        meta_d, status_d, scratch_d = plan[:B * _lib.META_WORDS], plan[B * _lib.META_WORDS:B * (_lib.META_WORDS + 1)], plan[B * (_lib.META_WORDS + 1):]
+        plan.zero_()
+        check(lib.nfst_pack_device_plan(C.byref(arcs), C.byref(opts), ws.data_ptr(), ws_bytes, meta_d.data_ptr(), status_d.data_ptr(),
+                                        scratch_d.data_ptr(), stream), "nfst_pack_device_plan")
+        plan_h = plan.cpu().numpy()  # the one read-back: 18 words per lattice
+        meta_h = np.ascontiguousarray(plan_h[:B * _lib.META_WORDS])
+        status_h = np.ascontiguousarray(plan_h[B * _lib.META_WORDS:B * (_lib.META_WORDS + 1)])
+        scratch_h = np.ascontiguousarray(plan_h[B * (_lib.META_WORDS + 1):])
+        header = _lib.Batch()
+        bad = C.c_int32(-1)
+        check(lib.nfst_pack_device_layout(meta_h.ctypes.data, status_h.ctypes.data, scratch_h.ctypes.data, B, int(vocab),
+                                          0 if w_d is None else 1, C.byref(header), C.byref(bad)), "nfst_pack_device_plan", bad.value)
+        h = {k: int(getattr(header, k)) for k in cls._HEADER}
+        sizes = cls._sizes(h)
+        tensors = {k: torch.empty(n, dtype=cls._DTYPES[k], device=dev) for k, n in sizes.items() if k != "meta"}
+        tensors["meta"] = torch.from_numpy(meta_h).to(dev)
+        tensors.setdefault("arc_w", None)
+        for k in cls._FIELDS:
+            t = tensors[k]
+            setattr(header, k, None if t is None or t.numel() == 0 else t.data_ptr())
+        check(lib.nfst_pack_device_emit(C.byref(arcs), C.byref(opts), ws.data_ptr(), ws_bytes, tensors["meta"].data_ptr(), status_d.data_ptr(),
+                                        C.byref(header), stream), "nfst_pack_device_emit")
+        out = cls.__new__(cls)
+        out._h, out._t, out._struct = h, tensors, None
+        out.meta_host = meta_h.reshape(-1, _lib.META_WORDS).copy()
+        out._keep = (ws, src_d, label_d, dst_d, w_d, small, n_rows_d, plan)  # alive until the emit launch has run
+        return out
+
+    @classmethod
+    def from_dense_device(cls, emission: torch.Tensor, transition: torch.Tensor, **pack_opts) -> "LatticeBatch":
+        """``from_dense`` for tables that live on the GPU: reachable rows -> arc lists (``nfst_dense_to_arcs_count`` /
+        ``_write``), then the device packer.  Two small read-backs (arc counts, the plan), no table leaves the GPU."""
+        if not (emission.is_cuda and transition.is_cuda) or emission.dim() != 3 or transition.shape != emission.shape:
+            raise ValueError("emission and transition must both be [B, S+1, V] tensors on the GPU")
+        dev = transition.device
+        B, R, V = transition.shape
+        is_float = emission.dtype.is_floating_point
+        em = emission.to(torch.float32).contiguous() if is_float else (emission if emission.dtype == torch.bool else emission != 0).contiguous()
+        tr = transition.to(torch.int64).contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        reach = torch.empty(B * R, dtype=torch.uint8, device=dev)
+        row_cnt = torch.empty(B * R, dtype=torch.int32, device=dev)
+        cs = torch.empty(2 * B, dtype=torch.int32, device=dev)
+        check(lib.nfst_dense_to_arcs_count(em.data_ptr(), 1 if is_float else 0, tr.data_ptr(), B, R, V, reach.data_ptr(), row_cnt.data_ptr(),
+                                           cs.data_ptr(), cs[B:].data_ptr(), stream), "nfst_dense_to_arcs_count")
+        cs_h = cs.cpu().numpy()
+        if cs_h[B:].any():
+            bad = int(np.nonzero(cs_h[B:])[0][0])
+            raise _lib.NfstError(int(cs_h[B + bad]), "nfst_dense_to_arcs_count", bad)
+        arc_off = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(cs_h[:B], out=arc_off[1:])
+        A = int(arc_off[-1])
+        arc_off_d = torch.from_numpy(arc_off).to(dev)
+        src = torch.empty(A, dtype=torch.int32, device=dev)
+        label, dst = torch.empty_like(src), torch.empty_like(src)
+        w = torch.empty(A, dtype=torch.float32, device=dev) if is_float else None
+        check(lib.nfst_dense_to_arcs_write(em.data_ptr(), 1 if is_float else 0, tr.data_ptr(), B, R, V, reach.data_ptr(), row_cnt.data_ptr(),
+                                           arc_off_d.data_ptr(), src.data_ptr(), label.data_ptr(), dst.data_ptr(),
+                                           None if w is None else w.data_ptr(), stream), "nfst_dense_to_arcs_write")
+        return cls.from_arcs_device(np.full(B, R, dtype=np.int32), arc_off, src, label, dst, V, arc_w=w, device=dev, **pack_opts)
 
     @classmethod
     def from_synth(cls, lattices: Sequence, device=None, **pack_opts) -> "LatticeBatch":
