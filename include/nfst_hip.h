@@ -239,7 +239,8 @@ int nfst_concat_packed(const nfst_batch *parts, int32_t n_parts, const nfst_batc
  *   nfst_pack_device_layout   (host) offsets into *meta, sizes and flags into *header: allocate the arrays, store their
  *                             device addresses in the header, upload meta (it is the batch's meta array)
  *   nfst_pack_device_emit     writes every array of the batch
- * ws: device workspace of nfst_pack_device_ws_bytes() bytes, contents irrelevant, may be reused at once.
+ * ws: device workspace of nfst_pack_device_ws_bytes() bytes.  The emitting pass reads what the planning pass of the same
+ * batch left there: the same workspace, untouched in between; free afterwards.
  */
 typedef struct nfst_arcs_device {
   const int32_t *n_rows;   /* [B] device */

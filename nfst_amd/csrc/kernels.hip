@@ -635,6 +635,11 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   return hip_status(hipGetLastError());
 }
 
+#ifdef NFST_PK_STAMPS
+extern "C" int nfst_debug_pk_stamps(unsigned long long *out) {  // profiling build only
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef NFST_NEU_STAMPS
 extern "C" int nfst_debug_neu_stamps(unsigned long long *out, int reset) {  // profiling build only
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(neu_stamps), sizeof(unsigned long long) * 128) != hipSuccess) return -1;

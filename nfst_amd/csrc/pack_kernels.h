@@ -167,7 +167,7 @@ __device__ __forceinline__ unsigned long long pk_key(int level, int pass, int g,
 
 // ---- one direction, one group mode: tile layout (count or emit) -------------------------------------------------------
 struct PkDir {
-  const int32_t *ord, *lvlp, *deg, *ptr, *list;  // level order, level starts, degrees, list pointers, arc list (canonical ids)
+  const int32_t *ord, *lvlp, *lev, *ptr, *list;  // level order, level starts, level of a state, list pointers, arc list (canonical ids)
   const int32_t *other;                         // other end of an arc, by canonical id (emit)
   const int32_t *lab;                           // label of an arc, by canonical id (emit)
   int n_reach, D, n_rows;
@@ -200,15 +200,6 @@ __device__ PkLayout pk_layout(const PkDir &d, int max_g, int vocab, unsigned lon
   // pieces per state -> offsets of their keys
   const int n_pieces = pk_scan<false>(n_st, [&](int i) { return pk_state_pieces(state_at(first_pos + i), cap); }, tmp_b, red);
   if (n_pieces > kPkMaxKeys || n_pieces + 1 > aux_cap) { out.err = NFST_ERR_LIMIT; return out; }
-  // level of a position: the level whose start is the last one <= pos (levels are short: a search over lvlp)
-  auto level_of = [&](int pos) {
-    int lo = 1, hi = d.D;  // lvlp[lo] <= pos < lvlp[hi + 1]
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (d.lvlp[mid] <= pos) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-  };
   auto full_state = [&](int pos, int level) {
     PkState st = state_at(pos);
     const int i = pos - first_pos;
@@ -231,7 +222,7 @@ __device__ PkLayout pk_layout(const PkDir &d, int max_g, int vocab, unsigned lon
   }
   // keys
   for (int i = threadIdx.x; i < n_st; i += kPkThreads) {
-    const int pos = first_pos + i, level = level_of(pos);
+    const int pos = first_pos + i, level = d.lev[d.ord[pos]];
     const PkState st = full_state(pos, level);
     int k = tmp_b[i];
     const int lp = pos - d.lvlp[level];
@@ -320,6 +311,76 @@ __device__ PkLayout pk_layout(const PkDir &d, int max_g, int vocab, unsigned lon
   return out;
 }
 
+// The planning pass only needs COUNTS: a (level, pass) segment of pieces takes ceil(sum of sizes / 64) tiles whatever
+// the order inside it, its wide tiles are ceil(sum of the sizes of groups beyond 8 lanes / 64) (those come first), and
+// the scratch rows of a level are the partial groups of its states.  One pass over the states with atomic adds into
+// tables indexed by (level, pass) in LDS -- no sort, no scan.  `table`: LDS, `words` int32 of room.  Returns err =
+// NFST_ERR_ARG when the tables do not fit (the caller then counts with pk_layout<false>).
+__device__ PkLayout pk_count_layout(const PkDir &d, int max_g, int32_t *table, int words, int aux_cap, int *red) {
+  PkLayout out{0, 0, 0, 0};
+  const int cap = (1 << max_g) * 4;
+  const int first_pos = d.lvlp[1], n_st = d.n_reach - first_pos;
+  if (n_st <= 0) return out;
+  auto state_at = [&](int pos) {
+    PkState st;
+    st.s = d.ord[pos];
+    st.b0 = d.ptr[st.s]; st.e0 = d.ptr[st.s + 1];
+    const int deg = st.e0 - st.b0;
+    st.tree = max_g == 3 && deg > 2 * cap;
+    st.n_part = st.tree ? (deg + cap - 1) / cap : 0;
+    st.first = 0;
+    return st;
+  };
+  // (the emitting pass sorts the pieces in LDS: what it cannot take is refused here, where the host still can fall back)
+  const int n_pieces = pk_count(n_st, [&](int i) { return pk_state_pieces(state_at(first_pos + i), cap); }, red);
+  if (n_pieces > kPkMaxKeys || n_pieces + 1 > aux_cap) { out.err = NFST_ERR_LIMIT; return out; }
+  // passes of the longest chain
+  int pmax_t = 1, P = 1;
+  for (int i = threadIdx.x; i < n_st; i += kPkThreads) {
+    const PkState st = state_at(first_pos + i);
+    pmax_t = max(pmax_t, st.tree ? 1 + pk_chain_pieces(st.n_part, cap) : pk_chain_pieces(st.e0 - st.b0, cap));
+  }
+  pk_block_excl<true>(pmax_t, red, &P);
+  __syncthreads();
+  const int L = d.D + 1;
+  if ((int64_t)L * (2 * P + 1) > words) { out.err = NFST_ERR_ARG; return out; }
+  int32_t *t_size = table, *t_wide = table + L * P, *t_scr = table + 2 * L * P;
+  for (int i = threadIdx.x; i < L * (2 * P + 1); i += kPkThreads) table[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_st; i += kPkThreads) {
+    const PkState st = state_at(first_pos + i);
+    const int level = d.lev[st.s];
+    auto add = [&](int pass, const PkPiece &p) {
+      atomicAdd(&t_size[level * P + pass], 1 << p.g);
+      if (p.g > 3) atomicAdd(&t_wide[level * P + pass], 1 << p.g);
+    };
+    if (st.tree) {
+      atomicAdd(&t_scr[level], st.n_part);
+      for (int j = 0; j < st.n_part; ++j) add(0, pk_piece(st, 0, j, cap));
+      const int nc = pk_chain_pieces(st.n_part, cap);
+      for (int c = 0; c < nc; ++c) add(1 + c, pk_piece(st, 1 + c, 0, cap));
+    } else {
+      const int nc = pk_chain_pieces(st.e0 - st.b0, cap);
+      for (int c = 0; c < nc; ++c) add(c, pk_piece(st, c, 0, cap));
+    }
+  }
+  __syncthreads();
+  out.tiles = pk_count(L * P, [&](int i) { return (t_size[i] + 63) >> 6; }, red);
+  out.wide = pk_count(L * P, [&](int i) { return (t_wide[i] + 63) >> 6; }, red);
+  int scr_t = 0;
+  for (int i = threadIdx.x; i < L; i += kPkThreads) scr_t = max(scr_t, t_scr[i]);
+  pk_block_excl<true>(scr_t, red, &out.scratch);
+  __syncthreads();
+  if (d.n_rows + out.scratch > NFST_MAX_ROWS) out.err = NFST_ERR_LIMIT;  // (pack.cpp then chains instead: host packer)
+  return out;
+}
+
+#ifdef NFST_PK_STAMPS
+__device__ unsigned long long pk_stamps[32];
+#define PK_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) pk_stamps[(EMIT ? 16 : 0) + (k)] = wall_clock64(); } while (0)
+#else
+#define PK_STAMP(k) do { } while (0)
+#endif
 // ---- the packer: one workgroup per lattice -----------------------------------------------------------------------------
 template <bool EMIT>
 __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
@@ -352,6 +413,11 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
   int32_t *aux = a.ws + (size_t)kPkRowArrays * (a.total_rows + 2 * a.n_lattices) + (size_t)kPkArcArrays * a.total_arcs + aux_at;
   int32_t *pa_ = aux, *pb_ = aux + aux_total, *pc_ = aux + 2 * aux_total, *tile_bits = aux + 3 * aux_total;
 
+  // The emitting pass reads what the planning pass left in the workspace (depths, canonical ids, arc lists, level orders):
+  // the same workspace, untouched in between.
+  PK_STAMP(0);
+  int n_reach = EMIT ? meta[NFST_META_N_REACH] : 0, D = EMIT ? meta[NFST_META_DEPTH] : 0, sink = 0, n_arcs = 0, n_dp = 0;
+  if (!EMIT) {
   // ---- 0. the arcs are what the host packer accepts: ids in range, sorted by (src, label), one arc per (state, label)
   if (tid == 0) { sh[0] = 0x7fffffff; sh[1] = 0; }
   __syncthreads();
@@ -368,6 +434,7 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
     fail(code == 1 ? NFST_ERR_INDEX : code == 2 ? NFST_ERR_ARG : NFST_ERR_DETERMINISM);
     return;
   }
+  PK_STAMP(1);
   // ---- 1. reachability, depth (longest path from 0) and height (longest path to the sink) by relaxation in LDS
   int *dep = reinterpret_cast<int *>(pk_lds), *hei = dep + n;
   uint32_t *sd = reinterpret_cast<uint32_t *>(hei + n);  // src | dst << 16 of every arc when they fit beside
@@ -375,67 +442,91 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
   for (int s = tid; s < n; s += kPkThreads) { dep[s] = s == 0 ? 0 : -1; hei[s] = 0; }
   if (sd_in_lds) for (int i = tid; i < A; i += kPkThreads) sd[i] = (uint32_t)src[i] | ((uint32_t)dst[i] << 16);
   __syncthreads();
+  // One sweep over the arcs moves depths forward and heights back by a level at least.  First with the heights of ALL
+  // states (D + 2 sweeps on a lattice whose unreachable part is acyclic too: the heights of reachable states only depend
+  // on reachable states); if that does not settle -- junk arcs among unreachable states may form cycles -- again with
+  // the heights of reached states only (they start moving when their states are reached: 2 D + 2 sweeps at most).
   bool cyclic = false;
-  for (int it = 0;; ++it) {
-    if (tid == 0) sh[1] = 0;
-    __syncthreads();
-    int changed = 0;
-    for (int i = tid; i < A; i += kPkThreads) {
-      int s, d2;
-      if (sd_in_lds) { const uint32_t x = sd[i]; s = (int)(x & 0xffffu); d2 = (int)(x >> 16); }
-      else { s = src[i]; d2 = dst[i]; }
-      if (s == d2) continue;
-      const int ds = dep[s];
-      if (ds < 0) continue;
-      if (dep[d2] < ds + 1) { atomicMax(&dep[d2], ds + 1); changed = 1; }
-      const int hd = hei[d2];
-      if (hei[s] < hd + 1) { atomicMax(&hei[s], hd + 1); changed = 1; }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int cap_it = attempt == 0 ? n + 2 : 2 * n + 4;
+    cyclic = false;
+    if (attempt == 1) {
+      for (int s = tid; s < n; s += kPkThreads) { dep[s] = s == 0 ? 0 : -1; hei[s] = 0; }
+      __syncthreads();
     }
-    if (changed) sh[1] = 1;
+    if (tid == 0) { sh[4] = 0; sh[5] = 0; sh[6] = 0; }
     __syncthreads();
-    const int any = sh[1];
-    __syncthreads();
-    if (!any) break;
-    // (depth moves forward one level per sweep over the arcs at least; heights follow once their states are reached
-    // and move back one level per sweep: at most 2 D + 2 sweeps on an acyclic lattice)
-    if (it > 2 * n + 4) { cyclic = true; break; }
+    for (int it = 0;; ++it) {  // (three "something moved" flags take turns: one barrier per sweep)
+      int changed = 0;
+      for (int i = tid; i < A; i += kPkThreads) {
+        int s, d2;
+        if (sd_in_lds) { const uint32_t x = sd[i]; s = (int)(x & 0xffffu); d2 = (int)(x >> 16); }
+        else { s = src[i]; d2 = dst[i]; }
+        if (s == d2) continue;
+        const int ds = dep[s];
+        if (ds >= 0 && dep[d2] < ds + 1) { atomicMax(&dep[d2], ds + 1); changed = 1; }
+        if (attempt == 1 && ds < 0) continue;
+        const int hd = hei[d2];
+        if (hei[s] < hd + 1) { atomicMax(&hei[s], hd + 1); changed = 1; }
+      }
+      if (changed) sh[4 + it % 3] = 1;
+      if (tid == 0) sh[4 + (it + 2) % 3] = 0;  // the flag of the sweep after the next: nobody reads or sets it now
+      __syncthreads();
+      const int any = sh[4 + it % 3];
+      if (!any) break;
+      if (it > cap_it) { cyclic = true; break; }
+    }
+    if (!cyclic) break;
   }
-  for (int s = tid; s < n; s += kPkThreads) { g_dep[s] = dep[s]; g_hei[s] = hei[s]; g_in[s] = 0; g_out[s] = 0; cnt[s] = 0; }
+  // counters and the unordered in-arc lists live in LDS when they fit (global atomics on a few hot counters -- a state
+  // with hundreds of in-arcs -- cost more than everything else of this pass together)
+  const bool c_lds = (int64_t)5 * n * 4 <= kPkLdsBytes;
+  int *c_out = c_lds ? hei + n : g_out, *c_in = c_lds ? hei + 2 * n : g_in, *c_cnt = c_lds ? hei + 3 * n : cnt;
+  for (int s = tid; s < n; s += kPkThreads) { g_dep[s] = dep[s]; g_hei[s] = hei[s]; c_in[s] = 0; c_out[s] = 0; c_cnt[s] = 0; }
   __syncthreads();
+  PK_STAMP(2);
   // ---- 2. degrees over the arcs of reachable states (self loops are not part of the sweeps), sink
   for (int i = tid; i < A; i += kPkThreads) {
     const int s = src[i], d2 = dst[i];
-    if (g_dep[s] >= 0 && s != d2) { atomicAdd(&g_out[s], 1); atomicAdd(&g_in[d2], 1); }
+    if (dep[s] >= 0 && s != d2) { atomicAdd(&c_out[s], 1); atomicAdd(&c_in[d2], 1); }
   }
   __syncthreads();
-  const int n_reach = pk_count(n, [&](int s) { return g_dep[s] >= 0 ? 1 : 0; }, red);
-  const int sinks = pk_count(n, [&](int s) { return (g_dep[s] >= 0 && g_out[s] == 0) ? 1 : 0; }, red);
+  if (c_lds) for (int s = tid; s < n; s += kPkThreads) { g_out[s] = c_out[s]; g_in[s] = c_in[s]; }
+  n_reach = pk_count(n, [&](int s) { return dep[s] >= 0 ? 1 : 0; }, red);
+  const int sinks = pk_count(n, [&](int s) { return (dep[s] >= 0 && c_out[s] == 0) ? 1 : 0; }, red);
   if (sinks != 1) { fail(NFST_ERR_SINK); return; }
   if (cyclic) { fail(NFST_ERR_CYCLE); return; }
   if (tid == 0) sh[2] = 0;
   __syncthreads();
   for (int s = tid; s < n; s += kPkThreads)
-    if (g_dep[s] >= 0 && g_out[s] == 0) sh[2] = s;
+    if (dep[s] >= 0 && c_out[s] == 0) sh[2] = s;
   __syncthreads();
-  const int sink = sh[2], D = g_dep[sink];
+  sink = sh[2];
+  D = dep[sink];
+  PK_STAMP(3);
   // ---- 3. canonical arcs (arcs of reachable states, input order), out- and in-arc lists of the sweeps
-  const int n_arcs = pk_scan<false>(A, [&](int i) { return g_dep[src[i]] >= 0 ? 1 : 0; }, canon, red);
-  const int n_dp = pk_scan<false>(A, [&](int i) { return (g_dep[src[i]] >= 0 && src[i] != dst[i]) ? 1 : 0; }, in_tmp, red);
+  n_arcs = pk_scan<false>(A, [&](int i) { return dep[src[i]] >= 0 ? 1 : 0; }, canon, red);
+  n_dp = pk_scan<false>(A, [&](int i) { return (dep[src[i]] >= 0 && src[i] != dst[i]) ? 1 : 0; }, in_tmp, red);
   for (int i = tid; i < A; i += kPkThreads)
-    if (g_dep[src[i]] >= 0 && src[i] != dst[i]) out_list[in_tmp[i]] = canon[i];
-  pk_scan<false>(n + 1, [&](int s) { return s < n ? g_out[s] : 0; }, out_ptr, red);
-  pk_scan<false>(n + 1, [&](int s) { return s < n ? g_in[s] : 0; }, in_ptr, red);
+    if (dep[src[i]] >= 0 && src[i] != dst[i]) out_list[in_tmp[i]] = canon[i];
+  pk_scan<false>(n + 1, [&](int s) { return s < n ? c_out[s] : 0; }, out_ptr, red);
+  pk_scan<false>(n + 1, [&](int s) { return s < n ? c_in[s] : 0; }, in_ptr, red);
+  PK_STAMP(4);
   // in-arcs: placed in any order inside their destination's segment, then ranked by input position = the stable order
+  const bool t_lds = c_lds && ((int64_t)5 * n + n_dp) * 4 <= kPkLdsBytes;
+  int *place = t_lds ? hei + 4 * n : in_tmp;
   for (int i = tid; i < A; i += kPkThreads)
-    if (g_dep[src[i]] >= 0 && src[i] != dst[i]) in_tmp[in_ptr[dst[i]] + atomicAdd(&cnt[dst[i]], 1)] = i;
+    if (dep[src[i]] >= 0 && src[i] != dst[i]) place[in_ptr[dst[i]] + atomicAdd(&c_cnt[dst[i]], 1)] = i;
   __syncthreads();
   for (int p = tid; p < n_dp; p += kPkThreads) {
-    const int i = in_tmp[p], d2 = dst[i];
+    const int i = place[p], d2 = dst[i];
+    const int q0 = in_ptr[d2], q1 = in_ptr[d2 + 1];
     int rank = 0;
-    for (int q = in_ptr[d2]; q < in_ptr[d2 + 1]; ++q) rank += in_tmp[q] < i ? 1 : 0;
-    in_list[in_ptr[d2] + rank] = canon[i];
+    for (int q = q0; q < q1; ++q) rank += place[q] < i ? 1 : 0;
+    in_list[q0 + rank] = canon[i];
   }
   __syncthreads();
+  PK_STAMP(5);
   // ---- 4. level orders: states by (depth, in-degree falling, id) and by (height, out-degree falling, id)
   if (n_reach > kPkMaxKeys) { fail(NFST_ERR_LIMIT); return; }
   for (int dir = 0; dir < 2; ++dir) {
@@ -457,6 +548,8 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
     if (tid == 0) lvlp[D + 1] = n_reach;
     __syncthreads();
   }
+  PK_STAMP(6);
+  }  // (!EMIT)
   // canonical-id indexed views of the arcs (the lists hold canonical ids): other end and label
   // (emit: the canonical arrays themselves; plan: not needed)
   const int32_t arc_base = EMIT ? meta[NFST_META_ARC_OFF] : 0;
@@ -477,19 +570,21 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
       }
     // row pointers: arcs of the states before s (absolute ids), n + 1 entries
     int32_t *rp = const_cast<int32_t *>(a.out.row_ptr) + row_base + b;
-    for (int s = tid; s < n; s += kPkThreads) cnt[s] = 0;
+    int *rc = reinterpret_cast<int *>(pk_lds);  // arcs per row, counted in LDS
+    for (int s = tid; s < n; s += kPkThreads) rc[s] = 0;
     __syncthreads();
     for (int i = tid; i < A; i += kPkThreads)
-      if (g_dep[src[i]] >= 0) atomicAdd(&cnt[src[i]], 1);
+      if (g_dep[src[i]] >= 0) atomicAdd(&rc[src[i]], 1);
     __syncthreads();
-    pk_scan<false>(n + 1, [&](int s) { return s < n ? cnt[s] : 0; }, tmp_a, red);
+    pk_scan<false>(n + 1, [&](int s) { return s < n ? rc[s] : 0; }, tmp_a, red);
     for (int s = tid; s <= n; s += kPkThreads) rp[s] = arc_base + tmp_a[s];
     __syncthreads();
   }
+  PK_STAMP(7);
   // ---- 5. tile programs
   PkDir dirs[2];
-  dirs[0] = PkDir{ord_f, lvlp_f, g_in, in_ptr, in_list, EMIT ? a.out.arc_src + arc_base : nullptr, EMIT ? a.out.arc_label + arc_base : nullptr, n_reach, D, n};
-  dirs[1] = PkDir{ord_b, lvlp_b, g_out, out_ptr, out_list, EMIT ? a.out.arc_dst + arc_base : nullptr, EMIT ? a.out.arc_label + arc_base : nullptr, n_reach, D, n};
+  dirs[0] = PkDir{ord_f, lvlp_f, g_dep, in_ptr, in_list, EMIT ? a.out.arc_src + arc_base : nullptr, EMIT ? a.out.arc_label + arc_base : nullptr, n_reach, D, n};
+  dirs[1] = PkDir{ord_b, lvlp_b, g_hei, out_ptr, out_list, EMIT ? a.out.arc_dst + arc_base : nullptr, EMIT ? a.out.arc_label + arc_base : nullptr, n_reach, D, n};
   int tiles[2], wide[2], scratch_rows = 0;
   for (int dir = 0; dir < 2; ++dir) {
     if (!EMIT) {
@@ -498,9 +593,17 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
       int best_wide = 0;
       double best_cost = 0.0;
       bool have = false;
+      // (a wide program differs from the narrow one only if some state has more arcs than a narrow group holds)
+      int dmax_t = 0, dmax = 0;
+      for (int s = tid; s < n; s += kPkThreads) dmax_t = max(dmax_t, dirs[dir].ptr[s + 1] - dirs[dir].ptr[s]);
+      pk_block_excl<true>(dmax_t, red, &dmax);
+      __syncthreads();
       for (int w = 0; w < 2; ++w) {
         if ((a.group_mode == 1 && w) || (a.group_mode == 2 && !w)) continue;
-        const PkLayout l = pk_layout<false>(dirs[dir], w ? 6 : 3, a.vocab, pk_lds, tmp_a, tmp_b, pa_, pb_, pc_, tile_bits, aux_cap, red, nullptr, nullptr, 0);
+        if (w && dmax <= 32 && a.group_mode != 2) continue;  // no group beyond 8 lanes: the same program as the narrow one
+        PkLayout l = pk_count_layout(dirs[dir], w ? 6 : 3, reinterpret_cast<int32_t *>(pk_lds), (int)(kPkLdsBytes / 4), aux_cap, red);
+        if (l.err == NFST_ERR_ARG)  // (tables of levels x passes beyond LDS: count by laying the tiles out)
+          l = pk_layout<false>(dirs[dir], w ? 6 : 3, a.vocab, pk_lds, tmp_a, tmp_b, pa_, pb_, pc_, tile_bits, aux_cap, red, nullptr, nullptr, 0);
         if (l.err) { fail(l.err); return; }
         if (w && l.wide == 0 && a.group_mode != 2) continue;  // the same program as the narrow one
         const double cost = (double)l.tiles * (330.0 + 55.0 * 4 + (w ? 60.0 : 0.0)) + 450.0 * l.wide;
@@ -516,6 +619,7 @@ __global__ __launch_bounds__(kPkThreads) void k_pack_lattice(PkArgs a) {
       if (l.err || l.tiles != meta[dir ? NFST_META_BWD_TILES : NFST_META_FWD_TILES]) { fail(l.err ? l.err : NFST_ERR_ARG); return; }
     }
   }
+  PK_STAMP(8);
   if (!EMIT && tid == 0) {
     meta[NFST_META_N_ROWS] = n; meta[NFST_META_N_ARCS] = n_arcs; meta[NFST_META_FWD_TILES] = tiles[0]; meta[NFST_META_BWD_TILES] = tiles[1];
     meta[NFST_META_SINK] = sink; meta[NFST_META_N_REACH] = n_reach; meta[NFST_META_DEPTH] = D; meta[NFST_META_N_DP] = n_dp;

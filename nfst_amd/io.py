@@ -45,7 +45,7 @@ def packed_sidecar(npz_fname: str, which: str = "num") -> str:
 def load_packed(npz_fname: str, which: str = "num", cache: bool = True, verify: bool = True, validate: bool = True):
     """The ``num`` (or ``denom``) lattice of one example as a packed one-lattice batch.  The
     packer runs the first time an example is seen; its output is kept in a sidecar file beside
-    the ``.npz`` (``cache=True``) and only memory-mapped afterwards -- what a DataLoader worker
+    the ``.npz`` (``cache=True``) and only read back afterwards -- what a DataLoader worker
     does instead of shipping the 5 MB dense tables (``FSADataset.__getitem__``,
     dataset_reader.py:30-40).  A stale sidecar (older than the ``.npz``, packed for another ABI
     version, or failing its checksums / ``nfst_validate_batch``) is rebuilt."""
@@ -67,6 +67,29 @@ def load_packed(npz_fname: str, which: str = "num", cache: bool = True, verify: 
         lat.save(tmp)
         os.replace(tmp, side)  # workers may race for the same example
     return lat
+
+
+class PackedReader:
+    """Reads packed sidecars into a ring of ``slots`` reusable byte buffers (no fresh pages to fault in for every file:
+    2.7 ms per 0.9 MB file through a memory map, 0.6 ms through a fresh buffer, ~0.15 ms into a warm one on the boxes
+    of this pool).  A loaded batch is valid until its slot comes round again: gather ``slots`` examples at most --
+    typically one step's batch, ``collate_packed(..., arena=...)`` -- before reading on."""
+
+    def __init__(self, slots: int, verify: bool = True, validate: bool = True):
+        self.slots, self.verify, self.validate = max(1, int(slots)), verify, validate
+        self.bufs, self.turn = [None] * self.slots, 0
+
+    def load(self, fname: str):
+        import os
+
+        from .lattice import LatticeBatch
+
+        i = self.turn % self.slots
+        self.turn += 1
+        need = os.path.getsize(fname)
+        if self.bufs[i] is None or self.bufs[i].size < need:
+            self.bufs[i] = np.empty(int(need * 1.25) + 4096, dtype=np.uint8)
+        return LatticeBatch.load(fname, verify=self.verify, validate=self.validate, buffer=self.bufs[i])
 
 
 def collate_packed(examples, device=None, arena=None):

@@ -189,7 +189,10 @@ def test_proposal_sampler_replays_reference_sampler(dev, golden_dir):
     g = torch.Generator().manual_seed(3)
     u = torch.rand(max_length + 1, N, generator=g)
     log_q, samples, _ = sp.stateful_sample(N, uniforms=u)
-    assert samples.shape[0] == N and len(steps) == samples.shape[1] + 1
+    # (the loop reads the device-side "every walker has ended" counters every 8 steps: the network may have been asked
+    # for up to 7 steps past the last one, whose results are dropped; the reference synchronises at every step)
+    assert samples.shape[0] == N and samples.shape[1] + 1 <= len(steps) <= samples.shape[1] + 8
+    assert len(steps) % 8 == 0 or len(steps) == max_length + 1
     arcs = [O.dense_to_arcs(d["emission"][b], d["transition"][b]) for b in range(B)]
     s_np, q_np = samples.cpu().numpy(), log_q.cpu().numpy()
     for n in range(N):
