@@ -159,6 +159,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   VT *lds = reinterpret_cast<VT *>(lds_raw);
   constexpr int kTwSlot = PREC ? kSlotWordsP : kSlotWords2;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) NFST_STAMP(0);
   // this thread's label score: requested before anything waits for the meta record
   const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;
   const Meta m = load_meta(lat.meta, b);
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     for (int i = 0; i < 2 * kSweepFlags; ++i) flags[i] = 0;
   }
   __syncthreads();
+  if (tid == 0) NFST_STAMP(1);
   const bool want_post = posterior != nullptr || grad_theta != nullptr;
   const int a_begin = m.arc_off, a_end = m.arc_off + m.n_arcs;
   // the posterior pass works on groups of 4 arcs (16-byte loads / stores) over the
@@ -324,15 +326,17 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
     run_weights<kNE, EXTRA, TW, PREC>(xw8, my_u, my_prog, my_perm, my_tiles, ex, x_index, my_ring, R, bwd_side ? flags : flags + kSweepFlags,
                                       (const float2 *)th, (const float2 *)(bwd_side ? beta : alpha), tw_v2,
                                       lds_addr(flags + 2 * kSweepFlags) + (bwd_side ? 0 : 64 * kTrash) + lane * kTrash, lds_addr(xc), xc_first, lane);
+    if (TW && wv == 2) NFST_STAMP(6);
   } else if constexpr (TW) {
     if (wv < 2) {
       int *fl = bwd_side ? flags : flags + kSweepFlags;
       __builtin_amdgcn_s_setprio(3);  // (the chain: 45.8 -> 44.3 us at 256 lattices)
       // (every program is compact: four slots per lane)
       if constexpr (PREC) tile_sweep2p<kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
-      else if (tw_v2) tile_sweep2<4, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
+      else if (tw_v2) tile_sweep2<4, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane, bwd_side ? 5 : -1);
       else tile_sweep<4, true, kNE>(my_tiles, my_ring, R, fl, fl + 4, lane);
       __builtin_amdgcn_s_setprio(0);
+      NFST_STAMP(bwd_side ? 2 : 3);
     }
   } else if (wv < 4 || (!kSelf && (wv == 6 || wv == 7))) {
     run_sweep<EXTRA, kSelf, kAhead, kNE>(wv < 4 ? wv >> 1 : 2, my_u, my_wide, my_raw, RS, my_prog,
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   }
   if (kPre > 0 && want_post && tid >= kSweepThreads) preload_arcs();
   __syncthreads();
+  if (tid == 0) NFST_STAMP(4);
   const float2 zme = me_f2(beta[0]);
   if (tid == 0) {
     const double z = me_log64(beta[0]);
@@ -427,4 +432,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       for (int l = tid; l < lat.vocab; l += NT) gout[l] = gth[l];
     }
   }
+#ifdef NFST_PROF
+  __syncthreads();
+  if (tid == 0) NFST_STAMP(7);
+#endif
 }

@@ -635,6 +635,11 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   return hip_status(hipGetLastError());
 }
 
+#ifdef NFST_PROF
+extern "C" int nfst_prof_read(unsigned long long *out, int n) {  // profiling build only
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_prof), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef NFST_PK_STAMPS
 extern "C" int nfst_debug_pk_stamps(unsigned long long *out) {  // profiling build only
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;

@@ -1255,9 +1255,16 @@ __device__ __forceinline__ int tile_math3(const Dec2<U> &c, const v2f (&vv)[U], 
 // Four tiles per trip (the ring holds a multiple of four slots, so a trip's slots are consecutive and the fetch
 // addresses are one base plus immediates; tile t's wave is t mod 4, so the four flags -- one 16-byte read -- are
 // checked once per trip for the four tiles the trip fetches; `prog` is published every other tile).
+#ifdef NFST_PROF
+__device__ unsigned long long fb_prof[4096 * 8];  // per workgroup: stamps of the profiling build (profiles/tune/stamps.py)
+#define NFST_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) fb_prof[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define NFST_STAMP(k) do { } while (0)
+#endif
 template <int U, int NEF>
-__device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land, int lane) {
+__device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, int R, int *prog, const int *land, int lane, int prof_slot = -1) {
   static_assert(NEF == 4, "four tile waves per sweep");
+  (void)prof_slot;
   if (n_tiles <= 0) return;
   constexpr uint32_t SB = kSlotWords2 * 4;
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
@@ -1265,22 +1272,29 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
   // the four flags in one read: .x = min over the tiles T+1 .. T+3 of (their wave's flag - their offset): all three are decoded
   // iff it exceeds T; .y = the same for tile T+4, which the trip's last step fetches (with a ring of four slots that tile can only
   // be written once the trip has consumed its first tile)
-  auto group_margin = [&]() {
-    const v4u f = *(const volatile lds_v4u *)(uintptr_t)land_a;
-    return v2u{(uint32_t)min(min((int)f.y - 1, (int)f.z - 2), (int)f.w - 3), (uint32_t)((int)f.x - 4)};
-  };
+  // (the raw flag words are kept and the margins evaluated where they are tested, a tile or two later: evaluated at once
+  // they made hipcc wait for the flag read -- the youngest of nine LDS reads in flight -- in front of the tile's arithmetic)
+  auto flags_now = [&]() { return *(const volatile lds_v4u *)(uintptr_t)land_a; };
+  // (every word of a copy is kept alive until the copy is looked at -- the empty asm statements below --: with dead words hipcc
+  // reused their registers at once and put a full wait for the flag read, the youngest of nine LDS reads in flight, in front of
+  // the tile's arithmetic)
+  auto margin_x = [](const v4u f) { return min(min((int)f.y - 1, (int)f.z - 2), (int)f.w - 3); };
+  auto margin_y = [](const v4u f) { return (int)f.x - 4; };
   auto wait_group = [&](int T, int which) {
     for (;;) {
-      const v2u g = group_margin();
-      if (__builtin_amdgcn_readfirstlane((int)(which ? g.y : g.x)) > T) break;
+      const v4u f = flags_now();
+      if (__builtin_amdgcn_readfirstlane(which ? margin_y(f) : margin_x(f)) > T) break;
       __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
   };
   while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32 *)(uintptr_t)land_a) <= 0) __builtin_amdgcn_s_sleep(1);  // tile 0
   asm volatile("" ::: "memory");
+#ifdef NFST_PROF
+  if (prof_slot >= 0) NFST_STAMP(prof_slot);
+#endif
   uint32_t gbase = ring_base;  // slot of the trip's first tile
-  v2u margin = {0u, 0u};       // group_margin() as of an earlier tile (per-lane copy)
+  v4u margin = {0u, 0u, 0u, 0u}, margin1 = {0u, 0u, 0u, 0u};  // the flag words as of an earlier tile (per-lane copies): nothing decoded beyond tile 0 is assumed
   int ref = 0;     // the exponent the terms of a tile are aligned to (wave-uniform, a few tiles old)
   int dmax0 = 0;
   Dec2<U> da, db;
@@ -1295,10 +1309,12 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
     __builtin_amdgcn_sched_barrier(0); /* nothing is scheduled in front of the operand gathers */         \
     if (K == 3) {                                                                                         \
       gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;                                  \
-      if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.y) <= T, 0)) wait_group(T, 1);      \
+      asm volatile("" ::"v"(margin1));                                                                    \
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin_y(margin1)) <= T, 0)) wait_group(T, 1);     \
     }                                                                                                     \
     dec2_fetch<U>(gbase + (K == 3 ? 0u : (K + 1) * SB), lane, NXT);                                       \
-    if (K == 1 || K == 3) margin = group_margin();                                                        \
+    if (K == 1) margin1 = flags_now();                                                                     \
+    if (K == 3) margin = flags_now();                                                        \
     asm volatile("" ::: "memory");                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     const int dm_ = tile_math3<U>(CUR, vv, ref);                                                          \
@@ -1309,7 +1325,8 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
   }
   int T = 0;
   for (; T + 4 <= n_tiles; T += 4) {  // whole trips: no end-of-program test between the tiles
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
+    asm volatile("" ::"v"(margin));
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin_x(margin)) <= T, 0)) wait_group(T, 0);
     NFST_S2_STEP(0, da, db)
     NFST_S2_STEP(1, db, da)
     NFST_S2_STEP(2, da, db)
@@ -1319,7 +1336,8 @@ __device__ __forceinline__ void tile_sweep2(int n_tiles, const uint32_t *ring, i
     ref = __builtin_amdgcn_readfirstlane((e0 > -(1 << 27)) ? e0 + ref : ref);  // (kept in a scalar register)
   }
   if (T < n_tiles) {  // the last one to three tiles
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
+    asm volatile("" ::"v"(margin));
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin_x(margin)) <= T, 0)) wait_group(T, 0);
     NFST_S2_STEP(0, da, db)
     if (T + 1 < n_tiles) {
       NFST_S2_STEP(1, db, da)
@@ -1424,14 +1442,17 @@ __device__ __forceinline__ void tile_sweep2p(int n_tiles, const uint32_t *ring, 
   constexpr uint32_t SB = kSlotWordsP * 4;
   const uint32_t ring_base = lds_addr(ring), ring_end = ring_base + (uint32_t)R * SB;
   const uint32_t land_a = lds_addr(land), prog_a = lds_addr(prog);
-  auto group_margin = [&]() {  // (as in tile_sweep2)
-    const v4u f = *(const volatile lds_v4u *)(uintptr_t)land_a;
-    return v2u{(uint32_t)min(min((int)f.y - 1, (int)f.z - 2), (int)f.w - 3), (uint32_t)((int)f.x - 4)};
-  };
+  // (as in tile_sweep2)
+  auto flags_now = [&]() { return *(const volatile lds_v4u *)(uintptr_t)land_a; };
+  // (every word of a copy is kept alive until the copy is looked at -- the empty asm statements below --: with dead words hipcc
+  // reused their registers at once and put a full wait for the flag read, the youngest of nine LDS reads in flight, in front of
+  // the tile's arithmetic)
+  auto margin_x = [](const v4u f) { return min(min((int)f.y - 1, (int)f.z - 2), (int)f.w - 3); };
+  auto margin_y = [](const v4u f) { return (int)f.x - 4; };
   auto wait_group = [&](int T, int which) {
     for (;;) {
-      const v2u g = group_margin();
-      if (__builtin_amdgcn_readfirstlane((int)(which ? g.y : g.x)) > T) break;
+      const v4u f = flags_now();
+      if (__builtin_amdgcn_readfirstlane(which ? margin_y(f) : margin_x(f)) > T) break;
       __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
@@ -1439,7 +1460,7 @@ __device__ __forceinline__ void tile_sweep2p(int n_tiles, const uint32_t *ring, 
   while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32 *)(uintptr_t)land_a) <= 0) __builtin_amdgcn_s_sleep(1);  // tile 0
   asm volatile("" ::: "memory");
   uint32_t gbase = ring_base;
-  v2u margin = {0u, 0u};
+  v4u margin = {0u, 0u, 0u, 0u}, margin1 = {0u, 0u, 0u, 0u};
   int ref = 0;
   int dmax0 = 0;
   Dec2P da, db;
@@ -1453,10 +1474,12 @@ __device__ __forceinline__ void tile_sweep2p(int n_tiles, const uint32_t *ring, 
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     if (K == 3) {                                                                                         \
       gbase = (gbase + 4 * SB == ring_end) ? ring_base : gbase + 4 * SB;                                  \
-      if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.y) <= T, 0)) wait_group(T, 1);      \
+      asm volatile("" ::"v"(margin1));                                                                    \
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin_y(margin1)) <= T, 0)) wait_group(T, 1);     \
     }                                                                                                     \
     dec2p_fetch(gbase + (K == 3 ? 0u : (K + 1) * SB), lane, NXT);                                         \
-    if (K == 1 || K == 3) margin = group_margin();                                                        \
+    if (K == 1) margin1 = flags_now();                                                                     \
+    if (K == 3) margin = flags_now();                                                        \
     asm volatile("" ::: "memory");                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     const int dm_ = tile_math3p(CUR, vv, ref);                                                            \
@@ -1467,7 +1490,8 @@ __device__ __forceinline__ void tile_sweep2p(int n_tiles, const uint32_t *ring, 
   }
   int T = 0;
   for (; T + 4 <= n_tiles; T += 4) {
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
+    asm volatile("" ::"v"(margin));
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin_x(margin)) <= T, 0)) wait_group(T, 0);
     NFST_S2P_STEP(0, da, db)
     NFST_S2P_STEP(1, db, da)
     NFST_S2P_STEP(2, da, db)
@@ -1476,7 +1500,8 @@ __device__ __forceinline__ void tile_sweep2p(int n_tiles, const uint32_t *ring, 
     ref = __builtin_amdgcn_readfirstlane((e0 > -(1 << 27)) ? e0 + ref : ref);
   }
   if (T < n_tiles) {
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)margin.x) <= T, 0)) wait_group(T, 0);
+    asm volatile("" ::"v"(margin));
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(margin_x(margin)) <= T, 0)) wait_group(T, 0);
     NFST_S2P_STEP(0, da, db)
     if (T + 1 < n_tiles) {
       NFST_S2P_STEP(1, db, da)
