@@ -350,6 +350,19 @@ def window_stats(windows):
     return {"n_windows": int(w.size), "min_ms": float(w.min()), "median_ms": float(np.median(w)), "max_ms": float(w.max())}
 
 
+def global_shard(G, world, rank, width):
+    """The job's G lattices (seeds 1234 + i) split over the ranks as the engine's callers would
+    (SURVEY 8e): every rank draws the G lattice sizes -- the state count S_i comes from the lattice's seed
+    alone, the arc count is ~10 S_i --, computes ``distributed.shard_lattices`` (greedy LPT, the same answer on
+    every rank, nothing is exchanged) and generates only its own lattices.  Returns (indices, lattices)."""
+    import numpy as np
+    from nfst_amd import synth
+    from nfst_amd.distributed import shard_lattices
+    S = [int(np.random.default_rng((1234 + i) ^ 0x5EED).integers(1800, 2201)) for i in range(G)]
+    mine = shard_lattices([10 * x for x in S], world)[rank]
+    return mine, [synth.layered_lattice(1234 + i, n_states=S[i], width=width) for i in mine]
+
+
 def build_batch(B, rank, width, dev, first_seed=None, **pack):
     from nfst_amd import synth
     from nfst_amd.lattice import LatticeBatch
@@ -497,7 +510,16 @@ def main():
 
     B = args.lattices_per_gpu or (256 if world == 1 else 1024)
     pack = dict(slots_per_lane=args.slots, group_mode=args.group_mode, no_compact=args.no_compact)
-    lats, lat, pack_s = build_batch(B, rank, args.width, dev, **pack)
+    shard = None
+    if world > 1:
+        # the real sharding path: LPT over the job's B * world lattices, every rank packs its own shard
+        from nfst_amd.lattice import LatticeBatch
+        shard, lats = global_shard(B * world, world, rank, args.width)
+        t0 = time.perf_counter()
+        lat = LatticeBatch.from_synth(lats, **pack).to(dev)
+        pack_s = time.perf_counter() - t0
+    else:
+        lats, lat, pack_s = build_batch(B, rank, args.width, dev, **pack)
     theta_np = synth.label_scores(1, 256)
     theta = torch.from_numpy(theta_np).to(dev)
     arcs = int(lat.n_dp_arcs.sum())
@@ -551,6 +573,31 @@ def main():
         _, win_r, _ = timed_region(st, max(8, min(args.steps, 64)), 4, world, dev, args.event_every)
         replay_ms = float(np.mean(win_r))
     replay_frac = None if replay_ms is None else lat.algorithmic_bytes() / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    # multi-rank: the per-lattice scores reassembled in job order on every rank (decode-style callers), checked against
+    # the oracle on a sample of this rank's own lattices; stragglers made visible (per-rank kernel time, arcs per rank)
+    sharding = None
+    if world > 1:
+        import torch.distributed as dist
+        from nfst_amd.distributed import gather_logz
+        from oracle import oracle as O
+        G = B * world
+        full = gather_logz(st.out.logz64, shard, G)
+        err = 0.0
+        for j in range(0, len(lats), max(1, len(lats) // 4)):
+            l = lats[j]
+            o = O.forward_backward(l.n_rows, l.src, l.dst, theta_np[l.label].astype(np.float64))
+            err = max(err, abs(float(full[shard[j]]) - o["logZ"]))
+        stats = torch.tensor([kern_ms, float(arcs), float(lat.n_lattices), err], dtype=torch.float64, device=dev)
+        allst = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allst, stats)
+        allst = torch.stack(allst).cpu().numpy()
+        sharding = {"global_batch": G, "policy": "greedy LPT by estimated arcs (10 x states), computed on every rank",
+                    "lattices_per_rank": [int(x) for x in allst[:, 2]], "arcs_per_rank": [int(x) for x in allst[:, 1]],
+                    "lpt_imbalance_max_over_mean_arcs": float(allst[:, 1].max() / allst[:, 1].mean()),
+                    "kernel_ms_per_rank_min": float(allst[:, 0].min()), "kernel_ms_per_rank_max": float(allst[:, 0].max()),
+                    "gathered_logz_max_abs_err_vs_oracle_sample": float(allst[:, 3].max()),
+                    "gathered_logz_finite": bool(torch.isfinite(full).all())}
+        assert sharding["gathered_logz_max_abs_err_vs_oracle_sample"] <= 1e-5, sharding
     del rotor, steppers[1:]
 
     # the other per-GPU batch size of the BASELINE configs, every rank, same protocol, fewer steps
@@ -598,7 +645,7 @@ def main():
             "config": {"workload": f"{shape}: {B} synthetic lattices per GPU, ~2k states / ~20k arcs "
                                    f"(layer width {args.width}), alpha+beta+logZ+arc posteriors",
                        "lattices_per_gpu": B, "lattices_total": B * world, "arcs_per_gpu": arcs, "vocab": 256,
-                       "resident_batches_rotated": n_rot,
+                       "resident_batches_rotated": n_rot, "sharding": sharding,
                        "cache_state": ("cold: %d distinct resident batches take turns, ~%.0f MB touched between two uses of a line "
                                        "(Infinity Cache: 256 MiB)" % (n_rot, (n_rot - 1) * touched / 1e6)) if n_rot > 1 else
                                       ("one resident batch, ~%.0f MB touched per launch" % (touched / 1e6)),
@@ -632,26 +679,44 @@ def main():
 
 
 def rehearse_cpu(args, rank, world):
-    """The launcher and the rank plumbing on a box without a GPU: gloo rendezvous, the host packer on a
-    few small lattices, one all-reduce.  Measures nothing and says so."""
+    """The launcher, the rank plumbing and the sharding path on a box without a GPU: gloo rendezvous, LPT sharding of
+    a small job computed on every rank, the host packer on each rank's shard, the scalar all-reduce and ``gather_logz``
+    (with a stand-in score per lattice: no kernel runs here).  Measures nothing and says so."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from nfst_amd import synth
-    from nfst_amd.distributed import all_reduce_loss
+    from nfst_amd.distributed import all_reduce_loss, gather_logz, shard_lattices
     from nfst_amd.lattice import LatticeBatch
 
     if world > 1:
         dist.init_process_group("gloo")
-    lats = [synth.layered_lattice(1234 + rank * 4 + i, n_states=60, avg_degree=4.0, vocab=32, width=4, span=2) for i in range(4)]
-    lat = LatticeBatch.from_synth(lats)
-    arcs = torch.tensor([float(lat.n_dp_arcs.sum())], dtype=torch.float64)
-    total = all_reduce_loss(arcs)
+    G = 6 * world + 1
+    sizes = [30 + 17 * (i % 5) + 9 * (i % 3) for i in range(G)]
+
+    def make(i):
+        return synth.layered_lattice(1234 + i, n_states=sizes[i], avg_degree=4.0, vocab=32, width=4, span=2)
+
+    shards = shard_lattices([4 * x for x in sizes], world)  # every rank, same answer, nothing exchanged
+    mine = shards[rank]
+    lat = LatticeBatch.from_synth([make(i) for i in mine])
+    score = torch.from_numpy(lat.n_dp_arcs.astype(np.float64))  # stand-in for log Z: the packed arc count of every lattice
+    total = all_reduce_loss(score.sum().reshape(1))
+    full = gather_logz(score, mine, G)
+    arcs = torch.zeros(world, dtype=torch.float64)
+    arcs[rank] = float(score.sum())
     if world > 1:
+        dist.all_reduce(arcs)
         dist.barrier()
     if rank == 0:
+        single = LatticeBatch.from_synth([make(i) for i in range(G)]).n_dp_arcs.astype(np.float64)  # one process, whole job
         print(json.dumps({"metric": "lattice-arcs/sec forward-backward (log-Z)", "value": None, "unit": "lattice-arcs/s",
                           "n_gpus": world, "rehearsal": "cpu: no kernel was run, nothing was measured",
-                          "arcs_packed_all_ranks": int(total.item())}), flush=True)
+                          "arcs_packed_all_ranks": int(total.item()),
+                          "sharding": {"global_batch": G, "lattices_per_rank": [len(x) for x in shards],
+                                       "lpt_imbalance_max_over_mean_arcs": float(arcs.max() / arcs.mean()),
+                                       "gathered_matches_single_process": bool(np.array_equal(full.numpy(), single)),
+                                       "sum_matches_single_process": bool(abs(float(total.item()) - single.sum()) < 1e-9)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1406,12 +1406,37 @@ __device__ __forceinline__ int tile_math3p(const Dec2P &c, const Rec64 (&vv)[4],
   constexpr int kZeroish = -(1 << 27);
   const uint32_t wide = (c.dst >> 25) & 1u;  // the tile's largest group exceeds 8 lanes (same in every lane)
   const uint64_t bad = __builtin_amdgcn_ballot_w64((((uint32_t)(dmax + 900) > 1800u) & (dmax > kZeroish)) | (wide != 0));
+  // (v_ldexp_f64 takes any int32 exponent: an exact zero's exponent, about -2^28, gives zero)
+#ifdef NFST_P_CLAMP
   double M = ldexp_clamped(mt[0], d[0]);
 #pragma unroll
   for (int j = 1; j < 4; ++j) M += ldexp_clamped(mt[j], d[j]);
+#else
+  double M = ldexp(mt[0], d[0]);
+#pragma unroll
+  for (int j = 1; j < 4; ++j) M += ldexp(mt[j], d[j]);
+#endif
+  // the three stages: partner's value by two v_mov_b32_dpp (every lane has a partner: the destination needs no initial
+  // value), times the 0 / 1 multiplier whose high word the tile wave left in the slot
+#ifdef NFST_P_BUILTINDPP
   M = fma(dpp_d<0xB1>(M), __hiloint2double((int)c.k0, 0), M);
   M = fma(dpp_d<0x4E>(M), __hiloint2double((int)c.k1, 0), M);
   M = fma(dpp_d<0x141>(M), __hiloint2double((int)c.k2, 0), M);
+#else
+  {
+    int plo, phi;
+#define NFST_DPP_PAIR(CTRL)                                                                                              \
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 " CTRL      \
+                 " row_mask:0xf bank_mask:0xf" : "=&v"(plo), "=&v"(phi) : "v"(__double2loint(M)), "v"(__double2hiint(M)))
+    NFST_DPP_PAIR("quad_perm:[1,0,3,2]");
+    M = fma(__hiloint2double(phi, plo), __hiloint2double((int)c.k0, 0), M);
+    NFST_DPP_PAIR("quad_perm:[2,3,0,1]");
+    M = fma(__hiloint2double(phi, plo), __hiloint2double((int)c.k1, 0), M);
+    NFST_DPP_PAIR("row_half_mirror");
+    M = fma(__hiloint2double(phi, plo), __hiloint2double((int)c.k2, 0), M);
+#undef NFST_DPP_PAIR
+  }
+#endif
   int E = ref;
   if (__builtin_expect(bad != 0, 0)) {
     const int g = (int)((c.dst >> 20) & 7u);
@@ -1429,6 +1454,12 @@ __device__ __forceinline__ int tile_math3p(const Dec2P &c, const Rec64 (&vv)[4],
 }
 __device__ __forceinline__ Rec64 rec64_load(uint32_t a) {
   const v4u x = *(const lds_v4u *)(uintptr_t)a;
+  // (the pad word is dead, so hipcc reads 8 + 4 bytes in two instructions -- and that is the fast form: kept alive as one
+  // ds_read_b128 per operand these random gathers cost 70 ns more per tile, 209 against 156 us on the SNIPS-shaped batch;
+  // profiles/tune/ab_precise.sh)
+#ifdef NFST_P_B128
+  asm volatile("" ::"v"(x));
+#endif
   Rec64 r;
   r.m = __hiloint2double((int)x.y, (int)x.x);
   r.e = (int)x.z;

@@ -1,11 +1,11 @@
 #!/bin/bash
 # How the files in profiles/ are produced (run on the GPU box through gpurun from the repo root):
-#   profiles/collect.sh r01
+#   profiles/collect.sh r03
 # 1. kernel trace + stats of the benchmark command  -> <tag>_kernel_stats.csv
 # 2. HBM traffic counters, one pass each            -> <tag>_pmc_traffic.json
 #    (MI355X_MICROARCH.md, "HBM": FETCH_SIZE and WRITE_SIZE are reported in KiB;
 #     on gfx950 FETCH_SIZE reads half of a wide coalesced streaming read)
-TAG=${1:-r01}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
@@ -33,6 +33,15 @@ for name in ("fetch", "write"):
         out[k] = {"mean_per_dispatch_KiB": sum(v) / len(v), "dispatches": len(v)}
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 50 --warmup 10; "
                "values in KiB per k_forward_backward dispatch; gfx950 FETCH_SIZE counts 64 B per 128-B streaming request")
+# the workload the counters were taken on (bench.py attaches a traffic file only to the same workload)
+try:
+    line = [l for l in open("$OUT/bench_under_rocprof.json") if l.startswith("{")][-1]
+    cfg = json.loads(line)["config"]
+    out["lattices_per_gpu"] = cfg["lattices_per_gpu"]
+    out["rotate"] = cfg.get("resident_batches_rotated", 1)
+    out["cache_state"] = cfg.get("cache_state")
+except Exception as e:
+    out["workload_error"] = str(e)
 json.dump(out, open("$R/gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
