@@ -459,6 +459,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a HIP graph of the step instead of launching from Python "
                     "(measured slower on ROCm 7.2: 67.8 vs 59.2 us per step)")
     ap.add_argument("--event-every", type=int, default=8, help="HIP events around runs of n back-to-back launches (4 when steps < 32)")
+    ap.add_argument("--no-replay", action="store_true", help="skip the extra loop that replays one resident batch (profiles/collect.sh: "
+                    "the rocprofv3 summary then averages cold launches only)")
     ap.add_argument("--rotate", type=int, default=0,
                     help="distinct resident batches the timed loop rotates over (0 = as many as it takes to push more than "
                          "the 256 MiB Infinity Cache between two uses of a line: 4 at 256 lattices per GPU, 1 from 1024 on)")
@@ -569,7 +571,7 @@ def main():
     alg_bytes = float(np.mean([s_.lat.algorithmic_bytes("forward_backward") for s_ in steppers]))
     # the same step replaying ONE resident batch (what rounds 1-2 reported): its ~131 MB per launch fit the Infinity Cache
     replay_ms = None
-    if n_rot > 1:
+    if n_rot > 1 and not args.no_replay:
         _, win_r, _ = timed_region(st, max(8, min(args.steps, 64)), 4, world, dev, args.event_every)
         replay_ms = float(np.mean(win_r))
     replay_frac = None if replay_ms is None else lat.algorithmic_bytes() / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -155,8 +155,8 @@ int nfst_device_available(void);
 /*
  * Launcher switches (tests and A/B measurements; every switch only selects among kernels that compute the same
  * function).  The environment variables of the same meaning -- NFST_TW, NFST_NO_FUSED, NFST_XCACHE, NFST_PRECISE,
- * NFST_NEU_PACK, NFST_NEU_NO_SMALL, NFST_LDS_RESERVE_KB -- are read once, when the first launcher runs, never on the
- * launch path.  name: "tw", "fused", "xcache", "neu_pack", "neu_small" (0 / 1), "precise" (0 never, 1 whenever it
+ * NFST_NEU_PACK, NFST_NEU_BF16, NFST_NEU_NO_SMALL, NFST_LDS_RESERVE_KB -- are read once, when the first launcher runs, never on the
+ * launch path.  name: "tw", "fused", "xcache", "neu_pack", "neu_bf16", "neu_small" (0 / 1), "precise" (0 never, 1 whenever it
  * fits, -1 by program depth: the default), "lds_reserve_kb" (0 .. 96).  Not thread-safe against concurrent launches.
  */
 int nfst_tuning_set(const char *name, int value);

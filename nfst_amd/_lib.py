@@ -150,7 +150,7 @@ def check(code: int, where: str, lattice: int = -1) -> None:
 class tuning:
     """``with tuning(tw=0, precise=0): ...`` -- launcher switches for tests and A/B measurements
     (``nfst_tuning_set``, include/nfst_hip.h); the defaults come back on exit."""
-    DEFAULTS = dict(tw=1, fused=1, xcache=1, precise=-1, neu_pack=1, neu_small=1)
+    DEFAULTS = dict(tw=1, fused=1, xcache=1, precise=-1, neu_pack=1, neu_small=1, neu_bf16=1)
 
     def __init__(self, **kw):
         unknown = set(kw) - set(self.DEFAULTS)

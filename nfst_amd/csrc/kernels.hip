@@ -103,6 +103,7 @@ struct Tuning {
   int xcache = 1;           // NFST_XCACHE=0: per-arc extras gathered from HBM / L2, never staged in LDS
   int precise = -1;         // NFST_PRECISE: 0 never, 1 whenever it fits, unset: programs deeper than kPreciseTiles tiles
   int neu_pack = 1;         // NFST_NEU_PACK=0: phase B reads Wh from the matrix itself
+  int neu_bf16 = 1;         // NFST_NEU_BF16=0: phase B on float32 MFMAs instead of three bfloat16 parts (hid a multiple of 64)
   int neu_small = 1;        // NFST_NEU_NO_SMALL=1: two-phase neural kernels for every hidden size
 };
 Tuning &tuning() {
@@ -116,6 +117,7 @@ Tuning &tuning() {
     r.xcache = num("NFST_XCACHE", 1) != 0;
     r.precise = (int)num("NFST_PRECISE", -1);
     r.neu_pack = num("NFST_NEU_PACK", 1) != 0;
+    r.neu_bf16 = num("NFST_NEU_BF16", 1) != 0;
     r.neu_small = getenv("NFST_NEU_NO_SMALL") ? 0 : 1;
     return r;
   }();
@@ -153,6 +155,7 @@ int nfst_tuning_set(const char *name, int value) {
   else if (n == "xcache") t.xcache = value != 0;
   else if (n == "precise") t.precise = value < 0 ? -1 : (value != 0);
   else if (n == "neu_pack") t.neu_pack = value != 0;
+  else if (n == "neu_bf16") t.neu_bf16 = value != 0;
   else if (n == "neu_small") t.neu_small = value != 0;
   else if (n == "lds_reserve_kb") t.lds_reserve = (value > 0 && value <= 96) ? (int64_t)value * 1024 : 0;
   else return NFST_ERR_ARG;
@@ -592,8 +595,8 @@ int nfst_proposal_step_backward(const nfst_batch *lat, const int64_t *value_stat
 
 int64_t nfst_neural_ws_floats(const nfst_batch *lat, int32_t hid) {
   if (!lat || hid <= 0) return NFST_ERR_ARG;
-  // u and beta_hat planes, (mantissa, exponent) rows, and Wh in MFMA fragment order (k_pack_mfma_b)
-  return neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1)) + (int64_t)hid * hid;
+  // u and beta_hat planes, (mantissa, exponent) rows, and Wh as three bfloat16 parts in MFMA fragment order (k_pack_mfma_b3)
+  return neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1)) + 2 * (int64_t)hid * hid;  // (+ Wh: float32 or 3 x bfloat16)
 }
 
 int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const float *wh, const float *w, int32_t hid,
@@ -603,11 +606,12 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   if (!label_x || !wh || !w || !log_beta || !beta_hat || !ws || hid <= 0) return NFST_ERR_ARG;
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   const int64_t lds = NeuLds(lat->max_rows, hid).bytes();
-  // phase B reads Wh in MFMA fragment order when hid is a multiple of 64 (NFST_NEU_PACK=0: from the matrix itself)
-  const int wh_packed = tuning().neu_pack && hid % 64 == 0;
+    // phase B on three bfloat16 parts when hid is a multiple of 64 (neu_pack = 0 or neu_bf16 = 0: float32 MFMAs from the matrix itself)
+  const int wh_packed = tuning().neu_pack && tuning().neu_bf16 && hid % 64 == 0;
+  float *wh_ws = ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1));
   if (wh_packed)
-    hipLaunchKernelGGL(k_pack_mfma_b, dim3((hid * hid / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh, (int)hid,
-                       reinterpret_cast<float4 *>(ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1))));
+    hipLaunchKernelGGL(k_pack_mfma_b3, dim3(((hid >> 4) * (hid >> 5) * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh, (int)hid,
+                       reinterpret_cast<uint4 *>(wh_ws));
 #define NFST_LAUNCH_NEU(HC)                                                                                   \
   do {                                                                                                        \
     if ((rc = set_lds(k_backward_neural<HC>, lds))) return rc;                                                \
@@ -655,7 +659,7 @@ extern "C" int nfst_debug_neu_stamps(unsigned long long *out, int reset) {  // p
 
 int64_t nfst_neural_grad_ws_floats(const nfst_batch *lat, int32_t hid) {
   if (!lat || hid <= 0) return NFST_ERR_ARG;
-  return neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid) + (int64_t)hid * hid;  // ... + Wh^T in fragment order
+  return neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid) + 2 * (int64_t)hid * hid;  // ... + Wh^T in fragment order (float32 or 3 x bfloat16)
 }
 
 int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const float *wh_t, const float *w, int32_t hid,
@@ -668,10 +672,12 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   if (lat->fwd_slots > 0 && !lat->fwd_perm) return NFST_ERR_ARG;
   const int64_t lds = NeuGradLds(lat->max_rows, hid).bytes();
-  const int wh_packed = tuning().neu_pack && hid % 64 == 0;
+  // phase B on three bfloat16 parts when hid is a multiple of 64 (neu_pack = 0 or neu_bf16 = 0: float32 MFMAs from the matrix itself)
+  const int wh_packed = tuning().neu_pack && tuning().neu_bf16 && hid % 64 == 0;
+  float *wh_ws = ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid);
   if (wh_packed)
-    hipLaunchKernelGGL(k_pack_mfma_b, dim3((hid * hid / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh_t, (int)hid,
-                       reinterpret_cast<float4 *>(ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid)));
+    hipLaunchKernelGGL(k_pack_mfma_b3, dim3(((hid >> 4) * (hid >> 5) * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh_t, (int)hid,
+                       reinterpret_cast<uint4 *>(wh_ws));
 #define NFST_LAUNCH_NEUG(HC)                                                                                       \
   do {                                                                                                             \
     if ((rc = set_lds(k_backward_neural_grad<HC>, lds))) return rc;                                                \

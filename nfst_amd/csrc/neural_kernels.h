@@ -66,7 +66,10 @@ struct NeuLds {
   // multiple of 16 (the K loop of phase B) + 4 floats so that the 16 rows of a pass start in different banks
   __host__ __device__ static int row_stride(int h) { return ((h + 15) & ~15) + 4; }
   // float2 beta[rows] | two staged tiles | float bh[32][row_stride]
-  __host__ __device__ int64_t bytes() const { return (int64_t)neu_rows_al(rows) * 8 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
+  __host__ __device__ int64_t bytes0() const { return (int64_t)neu_rows_al(rows) * 8 + 2 * kNeuStageWords * 4 + (int64_t)kNeuRows * row_stride(hid) * 4; }
+  // three bfloat16 planes (high / middle / low part of the 16 rows of a pass of phase B: neu_phase_b), rows of hid + 8 elements
+  __host__ __device__ static int64_t planes_bytes(int h) { return 3 * 16 * (int64_t)(h + 8) * 2; }
+  __host__ __device__ int64_t bytes() const { return ((bytes0() + 15) & ~(int64_t)15) + planes_bytes(hid); }
 };
 
 // tanh(x) = 1 - 2 / (e^2x + 1) on the hardware exp2 and reciprocal: absolute error below 2e-7 over
@@ -129,6 +132,19 @@ __device__ __forceinline__ float neu_load_fresh(const float *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// a = hi + mid + lo with bfloat16 parts rounded to nearest (the upper 16 bits of a float32 each): |a - (hi + mid + lo)| <= 2^-27 |a|,
+// and the products the split MFMAs drop (mid lo, lo mid, lo lo) are ~2^-26 of the result with random signs (truncated parts
+// leave them at 2^-23, all of one sign: 3.9e-5 on log beta at H = 512 against 3e-5 asked)
+__device__ __forceinline__ uint32_t neu_bf16_rn(float x) {
+  const uint32_t b = __float_as_uint(x);
+  return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
+}
+__device__ __forceinline__ void neu_split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {  // results in the upper halves
+  hi = neu_bf16_rn(a);
+  const float r1 = a - __uint_as_float(hi);
+  mid = neu_bf16_rn(r1);
+  lo = neu_bf16_rn(r1 - __uint_as_float(mid));
+}
 // Phase B of a tile: out(s) = M . row(s) for the states the tile finished, 16 of them per pass over
 // the matrix: D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32
 // (v_mfma_f32_16x16x4_f32), one block of 16 columns per wave.  A comes from the LDS rows phase A
@@ -137,7 +153,7 @@ __device__ __forceinline__ float neu_load_fresh(const float *p) {
 template <class RowOf, class Put>
 __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, const float *__restrict__ wh, int hid,
                                             const uint32_t *ctl_s, const int *lead_s, int tid, int wv, int lane,
-                                            RowOf row_of, Put put, const float4 *whp = nullptr) {
+                                            RowOf row_of, Put put, const uint4 *whb = nullptr, uint16_t *a3 = nullptr) {
   // ---- B: u = Wh . beta_hat for the states this tile wrote, 16 of them per pass over Wh:
   // D[16 states x 16 columns] += A[16 x 4] B[4 x 16] on the matrix cores in float32, one block of
   // 16 columns per wave.  A comes from the LDS rows phase A filled, B straight from Wh (L2).
@@ -155,6 +171,52 @@ __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, c
       rows = rows_s;
     }
     const int li = lane & 15, kq = lane >> 4;
+    if (whb) {
+      // Both factors as three bfloat16 parts (high, middle, low, rounded to nearest: neu_split3) and six
+      // v_mfma_f32_16x16x32_bf16 per 32 of K -- hh, hm, mh, hl, lh, mm; the dropped products are 2^-24 of the result -- instead
+      // of eight float32 MFMAs: 96 instead of 256 matrix-pipe cycles (round 2 found phase B bound by the float32 MFMA rate:
+      // 3.4 us of its ~7 us per tile at H = 256 with four waves per SIMD).  The matrix was split by k_pack_mfma_b3; the 16
+      // rows of this pass are split here, once for all sixteen waves, into three planes in LDS.
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      const int ps = hid + 8;  // plane row in elements: 16-byte aligned, and the 16 rows of a fragment read start 4 banks apart
+      __syncthreads();         // (the planes of the previous pass have been read)
+      for (int i = tid; i < 16 * hid; i += kNeuThreads) {
+        const int g = i / hid, h = i - g * hid;
+        const float a = g < n ? rows[g * hs + h] : 0.0f;
+        uint32_t hb, mb, lb;
+        neu_split3(a, hb, mb, lb);
+        a3[g * ps + h] = (uint16_t)(hb >> 16);
+        a3[(16 + g) * ps + h] = (uint16_t)(mb >> 16);
+        a3[(32 + g) * ps + h] = (uint16_t)(lb >> 16);
+      }
+      __syncthreads();
+      const int n_steps = hid >> 5;
+      for (int ct = wv; ct * 16 < hid; ct += kNeuWaves) {
+        const int col = ct * 16 + li;
+        f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const uint4 *bq = whb + (size_t)ct * n_steps * 3 * 64 + lane;
+        const uint16_t *ap = a3 + li * ps + 8 * kq;
+#pragma unroll 1  // (the gradient kernel is at its 128 registers: a second step in flight spills)
+        for (int st = 0; st < n_steps; ++st) {
+          const uint4 b0 = bq[(st * 3 + 0) * 64], b1 = bq[(st * 3 + 1) * 64], b2 = bq[(st * 3 + 2) * 64];
+          const uint4 a0 = *reinterpret_cast<const uint4 *>(ap + 32 * st), a1 = *reinterpret_cast<const uint4 *>(ap + 16 * ps + 32 * st),
+                      a2 = *reinterpret_cast<const uint4 *>(ap + 32 * ps + 32 * st);
+#define NFST_MM(A, B) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc, 0, 0, 0)
+          NFST_MM(a2, b0); NFST_MM(a0, b2); NFST_MM(a1, b1); NFST_MM(a1, b0); NFST_MM(a0, b1); NFST_MM(a0, b0);  // small terms first
+#undef NFST_MM
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // lane holds D[4 kq + r][li]
+          const int g = 4 * kq + r;
+          if (g < n && col < hid) {
+            const int sid = (int)((ctl_s[lead_s[g0 + g]] & 0xffffu) >> 3);
+            put(sid, col, acc[r]);
+          }
+        }
+      }
+      continue;
+    }
     for (int ct = wv; ct * 16 < hid; ct += kNeuWaves) {
       const int col = ct * 16 + li;
       typedef float f4 __attribute__((ext_vector_type(4)));
@@ -162,11 +224,10 @@ __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, c
       if ((hid & 15) == 0) {
         const float *bp = wh + (size_t)col * hid + 4 * kq;
         const float *ap = rows + li * hs + 4 * kq;
-        // B fragments: from the matrix itself (16 rows x 64 bytes per load instruction), or, when the launcher packed it
-        // (hid a multiple of 64, k_pack_mfma_b), from a copy laid out in fragment order -- one load instruction = 1 KiB of
-        // consecutive bytes.  Fragment-shaped loads queue in the load path: 7-8 us per tile at H = 256.
-        const float4 *b4 = whp ? whp + (size_t)ct * (hid >> 6) * 256 + lane : reinterpret_cast<const float4 *>(bp);
-        const int sd = whp ? 64 : 4, sh = whp ? 256 : 16;  // float4 strides per d and per 64 of K
+        // B fragments from the matrix itself (16 rows x 64 bytes per load instruction: hidden sizes that are not a multiple of
+        // 64, and the float32 reference path of the A/B switch `neu_bf16`; multiples of 64 take the split path above)
+        const float4 *b4 = reinterpret_cast<const float4 *>(bp);
+        constexpr int sd = 4, sh = 16;  // float4 strides per d and per 64 of K
         int h = 0;
         for (; h + 64 <= hid; h += 64) {  // four 16-byte loads of Wh in flight per lane
           float4 bq[4], aq[4];
@@ -208,16 +269,26 @@ __device__ __forceinline__ void neu_phase_b(float *rows_s, int hs, int n_lead, c
   }
 }
 
-// The matrix of phase B in MFMA fragment order (hid a multiple of 64): float4 number ((ct * hid/64 + c) * 4 + d) * 64 + lane
-// holds M[16 ct + (lane & 15)][64 c + 16 d + 4 (lane >> 4) + 0 .. 3], what lane `lane` of the wave with column block ct
-// loads at step c, d of its K loop.  One thread per float4; 256 KiB at H = 256, once per launch.
-__global__ __launch_bounds__(256) void k_pack_mfma_b(const float *__restrict__ mat, int hid, float4 *__restrict__ out) {
+// The matrix of phase B split in three bfloat16 parts, in the fragment order of v_mfma_f32_16x16x32_bf16 (hid a multiple of 64):
+// 16-byte word number (((ct * hid/32 + s) * 3 + part) * 64 + lane) holds part `part` of M[16 ct + (lane & 15)][32 s + 8 (lane >> 4) + 0 .. 7].
+// One thread per (ct, s, lane); 384 KiB at H = 256, once per launch.
+__global__ __launch_bounds__(256) void k_pack_mfma_b3(const float *__restrict__ mat, int hid, uint4 *__restrict__ out) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= hid * hid / 4) return;
-  const int lane = t & 63, d = (t >> 6) & 3, cc = t >> 8, nch = hid >> 6;
-  const int c = cc % nch, ct = cc / nch;
-  const float *p = mat + (size_t)(ct * 16 + (lane & 15)) * hid + c * 64 + 16 * d + 4 * (lane >> 4);
-  out[t] = make_float4(p[0], p[1], p[2], p[3]);
+  if (t >= (hid >> 4) * (hid >> 5) * 64) return;
+  const int lane = t & 63, cs = t >> 6, n_steps = hid >> 5;
+  const int st = cs % n_steps, ct = cs / n_steps;
+  const float *p = mat + (size_t)(ct * 16 + (lane & 15)) * hid + 32 * st + 8 * (lane >> 4);
+  uint32_t part[3][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint32_t hb, mb, lb;
+    neu_split3(p[j], hb, mb, lb);
+    const uint32_t v[3] = {hb >> 16, mb >> 16, lb >> 16};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) part[q][j >> 1] = (j & 1) ? (part[q][j >> 1] | (v[q] << 16)) : v[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) out[((size_t)cs * 3 + q) * 64 + lane] = make_uint4(part[q][0], part[q][1], part[q][2], part[q][3]);
 }
 // where the packed copy sits in a workspace of `used` floats (16-byte aligned)
 __host__ __device__ inline int64_t neu_pack_off(int64_t used) { return (used + 3) & ~(int64_t)3; }
@@ -232,7 +303,9 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
-  const float4 *whp = wh_packed ? reinterpret_cast<const float4 *>(ws + neu_pack_off(2 * (int64_t)lat.n_lattices * lat.max_rows * (hid + 1))) : nullptr;
+  const float *wh_ws = ws + neu_pack_off(2 * (int64_t)lat.n_lattices * lat.max_rows * (hid + 1));
+  const uint4 *whb = wh_packed ? reinterpret_cast<const uint4 *>(wh_ws) : nullptr;  // Wh as three bfloat16 parts, fragment order
+  uint16_t *a3 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds) + ((NeuLds(lat.max_rows, hid).bytes0() + 15) & ~(int64_t)15));
   float2 *bme = lds;
   uint32_t *stage_s = (uint32_t *)(bme + neu_rows_al(lat.max_rows));  // two tiles: kNeuStageWords each
   float *bh_s = (float *)(stage_s + 2 * kNeuStageWords);
@@ -405,7 +478,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural(nfst_batch lat,
     // ---- B: u = Wh . beta_hat for the states this tile wrote (real rows only)
     neu_phase_b(bh_s, hs, n_lead, wh, hid, ctl_s, lead_s, tid, wv, lane,
                 [&](int sid) { return (const float *)bh_row(sid); },
-                [&](int sid, int col, float v) { if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = v; }, whp);
+                [&](int sid, int col, float v) { if (sid < m.n_rows) u_w[(size_t)sid * hid + col] = v; }, whb, a3);
     const unsigned long long t_b = NEU_NOW();
     __threadfence_block();
     const unsigned long long t_f = NEU_NOW();
@@ -599,9 +672,10 @@ struct NeuGradLds {
   int rows, hid;
   __host__ __device__ NeuGradLds(int r, int h) : rows(r), hid(h) {}
   // float2 beta[rows] | float lambda[rows] | two staged tiles | float gamma[32][row_stride]
-  __host__ __device__ int64_t bytes() const {
+  __host__ __device__ int64_t bytes0() const {
     return (int64_t)neu_rows_al(rows) * 8 + (int64_t)((rows + 3) & ~3) * 4 + 2 * kNeuGradStageWords * 4 + (int64_t)kNeuRows * NeuLds::row_stride(hid) * 4 + 16;
   }
+  __host__ __device__ int64_t bytes() const { return ((bytes0() + 15) & ~(int64_t)15) + NeuLds::planes_bytes(hid); }
 };
 
 template <int HC>
@@ -613,7 +687,9 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Meta m = load_meta(lat.meta, b);
-  const float4 *whp = wh_packed ? reinterpret_cast<const float4 *>(ws + neu_pack_off(2 * (int64_t)lat.n_lattices * lat.max_rows * hid)) : nullptr;
+  const float *wh_ws = ws + neu_pack_off(2 * (int64_t)lat.n_lattices * lat.max_rows * hid);
+  const uint4 *whb = wh_packed ? reinterpret_cast<const uint4 *>(wh_ws) : nullptr;
+  uint16_t *a3 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds) + ((NeuGradLds(lat.max_rows, hid).bytes0() + 15) & ~(int64_t)15));
   float2 *bme = lds;
   float *lam = (float *)(bme + neu_rows_al(lat.max_rows));
   uint32_t *stage_s = (uint32_t *)(lam + ((lat.max_rows + 3) & ~3));
@@ -792,7 +868,7 @@ __global__ __launch_bounds__(kNeuThreads) void k_backward_neural_grad(
                 [&](int sid, int col, float v) {
                   if (sid < m.n_rows)
                     eta_w[(size_t)sid * hid + col] = v + (g_betahat ? g_betahat[((size_t)m.row_off + sid) * hid + col] : 0.0f);
-                }, whp);
+                }, whb, a3);
     __threadfence_block();
     __syncthreads();
   }

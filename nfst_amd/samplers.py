@@ -100,11 +100,12 @@ class ProposalSampler(Sampler):
     the transition row of the state before the previous symbol was consumed."""
 
     def __init__(self, model: LatticeScorer, score_fn, penalties: Optional[Dict] = None,
-                 beta_from_previous_state: bool = True):
+                 beta_from_previous_state: bool = True, sync_every: int = 8):
         super().__init__(model)
         self.score_fn = score_fn
         self.penalties = penalties
         self.beta_from_previous_state = beta_from_previous_state
+        self.sync_every = max(1, int(sync_every))  # steps between two looks at the device-side "every walker has ended" counters
 
     def stateful_sample(self, batch_size: int, to_evaluate: Optional[torch.Tensor] = None, hx=None,
                         temperature: float = 1.0, values: Optional[torch.Tensor] = None,
@@ -132,7 +133,7 @@ class ProposalSampler(Sampler):
         # the kernel counts into, read back every CHECK steps: one host-device synchronisation per CHECK steps instead
         # of one per step (the reference tests all_reached_eos at every step, samplers.py:288-290).  Steps that ran
         # past the first all-pad step are dropped again, hx included: results are those of the step-by-step loop.
-        CHECK = 8
+        CHECK = self.sync_every
         T = (m.max_length + 1) if not evaluate_only else min(m.max_length + 1, padded.shape[1])
         sym_all = torch.empty((T, batch_size), dtype=torch.int64, device=dev)
         nxt_all = torch.empty((T, batch_size), dtype=torch.int64, device=dev)

@@ -57,6 +57,25 @@ out["emission_mask_K64"] = {"ms": t * 1e3, "GB/s_written": 256 * 64 * 256 * 4 / 
 sc64 = torch.randn(256 * 64, 256, device=dev); u64 = torch.rand(256 * 64, device=dev)
 t = timeit(lambda: ops.proposal_step(lat, st, sc64, k=64, inp=lb, uniforms=u64))
 out["proposal_step_K64"] = {"ms": t * 1e3, "walkers/s": 256 * 64 / t, "note": "incl. the Python wrapper (4 output allocations)"}
+# the sampler loop (Sampler.stateful_sample, samplers.py:243-297): T ~ 300 steps, N = 2048 walkers, a network that costs nothing;
+# sync_every = 1 is the reference's protocol (all_reached_eos looked at, i.e. a device synchronisation, at every step)
+from nfst_amd.samplers import ProposalSampler
+from nfst_amd.scorers import LatticeScorer
+lats_s = [synth.layered_lattice(500 + i, n_states=1150, avg_degree=4.0, vocab=64, width=4, span=1, max_degree=12) for i in range(32)]
+sc = LatticeScorer(64, pad=0, bos=1, eos=2, max_length=300).to(dev)
+em_s, tr_s = synth.collate_dense([l.dense() for l in lats_s])
+zero_logits = torch.zeros(32 * 64, 64, device=dev)
+for every in (1, 8):
+    sp = ProposalSampler(sc, lambda hx, inp: (hx, zero_logits), sync_every=every)
+    sp.set_masks(transition=torch.from_numpy(tr_s), emission=torch.from_numpy(em_s))
+    sp.set_k(64)
+    with torch.no_grad():
+        sp.stateful_sample(32 * 64)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            lq, smp, _ = sp.stateful_sample(32 * 64)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 3
+    out[f"proposal_sampler_T{smp.shape[1]}_N2048_sync_every_{every}"] = {"ms": t * 1e3, "us_per_step": t / (smp.shape[1] + 1) * 1e6}
 t = timeit(lambda: ops.gather_label_scores(lat, theta))
 out["gather_label_scores"] = {"ms": t * 1e3, "GB/s": lat.total_arcs * 8 / t / 1e9}
 # neuralised beta: hid_dim of the reference's configs (conf/train/*.yaml: 256) and a small one

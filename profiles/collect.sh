@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
-CMD="python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-aux ${COLLECT_ARGS}"
+CMD="python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-aux --no-replay ${COLLECT_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD > /dev/null 2> $OUT/write.err
