@@ -606,8 +606,8 @@ int nfst_backward_neural(const nfst_batch *lat, const float *label_x, const floa
   if (!label_x || !wh || !w || !log_beta || !beta_hat || !ws || hid <= 0) return NFST_ERR_ARG;
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   const int64_t lds = NeuLds(lat->max_rows, hid).bytes();
-    // phase B on three bfloat16 parts when hid is a multiple of 64 (neu_pack = 0 or neu_bf16 = 0: float32 MFMAs from the matrix itself)
-  const int wh_packed = tuning().neu_pack && tuning().neu_bf16 && hid % 64 == 0;
+    // phase B on three bfloat16 parts when hid is a multiple of 64 from 256 on (neu_pack = 0 or neu_bf16 = 0: float32 MFMAs from the matrix itself)
+  const int wh_packed = tuning().neu_pack && tuning().neu_bf16 && hid % 64 == 0 && hid >= 256;  // (below 256 the split's two barriers per pass cost more than the matrix pipe gains: H = 128 1.41 against 1.39 ms)
   float *wh_ws = ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * (hid + 1));
   if (wh_packed)
     hipLaunchKernelGGL(k_pack_mfma_b3, dim3(((hid >> 4) * (hid >> 5) * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh, (int)hid,
@@ -672,8 +672,8 @@ int nfst_backward_neural_grad(const nfst_batch *lat, const float *label_x, const
   if (hid > kNeuMaxHid) return NFST_ERR_LIMIT;
   if (lat->fwd_slots > 0 && !lat->fwd_perm) return NFST_ERR_ARG;
   const int64_t lds = NeuGradLds(lat->max_rows, hid).bytes();
-  // phase B on three bfloat16 parts when hid is a multiple of 64 (neu_pack = 0 or neu_bf16 = 0: float32 MFMAs from the matrix itself)
-  const int wh_packed = tuning().neu_pack && tuning().neu_bf16 && hid % 64 == 0;
+  // phase B on three bfloat16 parts when hid is a multiple of 64 from 256 on (neu_pack = 0 or neu_bf16 = 0: float32 MFMAs from the matrix itself)
+  const int wh_packed = tuning().neu_pack && tuning().neu_bf16 && hid % 64 == 0 && hid >= 256;  // (below 256 the split's two barriers per pass cost more than the matrix pipe gains: H = 128 1.41 against 1.39 ms)
   float *wh_ws = ws + neu_pack_off(2 * (int64_t)lat->n_lattices * lat->max_rows * hid);
   if (wh_packed)
     hipLaunchKernelGGL(k_pack_mfma_b3, dim3(((hid >> 4) * (hid >> 5) * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wh_t, (int)hid,
