@@ -369,7 +369,12 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
       pp[q] = (s0 != d0) ? arc_posterior(me_f2(alpha[s0]), me_f2(beta[d0]), me_f2(th[ll[q]]), rz, ez, has_extra, xmv[q], xev[q]) : 0.0f;
       if (grad_theta && pp[q] > 0.0f) atomicAdd(&gth[ll[q]], pp[q]);
     }
-    if (posterior) *reinterpret_cast<float4 *>(posterior + a) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    if (posterior) {
+      // non-temporal: nobody reads the 20 MB of posteriors back inside this launch, and as ordinary stores they went through
+      // the L2 in one burst behind the barrier (39.6 -> 38.6 us cold, 36.0 -> 34.8 replayed; profiles/tune/ab_variants.sh)
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f4v{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f4v *>(posterior + a));
+    }
   };
   if (kPre > 0 && tid >= kSweepThreads && want_post) {
 #pragma unroll
@@ -381,8 +386,8 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   // the row outputs: every thread (the sweep waves start here, the others come when their preloaded
   // arc groups are done)
   for (int i = tid; i < m.n_rows; i += NT) {
-    if (logalpha) logalpha[m.row_off + i] = me_log32(alpha[i]);
-    if (logbeta) logbeta[m.row_off + i] = me_log32(beta[i]);
+    if (logalpha) __builtin_nontemporal_store(me_log32(alpha[i]), logalpha + m.row_off + i);
+    if (logbeta) __builtin_nontemporal_store(me_log32(beta[i]), logbeta + m.row_off + i);
     if (beta_me) beta_me[m.row_off + i] = me_f2(beta[i]);
   }
   if (want_post) {
