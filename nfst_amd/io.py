@@ -116,6 +116,7 @@ class DevicePrefetcher:
         self.batches = batches
         self.device = torch.device(device)
         self.depth = max(2, int(depth))
+        self._arenas = None  # page-locked once, on first use, and kept for every later pass over `batches`
 
     def __iter__(self):
         import torch
@@ -123,7 +124,9 @@ class DevicePrefetcher:
         from .lattice import HostArena, LatticeBatch
 
         side = torch.cuda.Stream(self.device)
-        arenas = [HostArena(pin=True) for _ in range(self.depth)]
+        if self._arenas is None:
+            self._arenas = [HostArena(pin=True) for _ in range(self.depth)]
+        arenas = self._arenas
         busy = [None] * self.depth  # the event after which an arena's buffers may be overwritten
         turn = [0]
 

@@ -42,13 +42,16 @@ with tempfile.TemporaryDirectory() as d:
     # ---- dense route (host packer) and dense_device route (tables to the GPU, packer there)
     t = {"load": 0.0, "collate": 0.0, "pack": 0.0, "h2d+fb": 0.0}
     td = {"h2d_tables": 0.0, "device_pack": 0.0, "fb": 0.0}
+    # (warm-up: the first launch of a kernel pays for its code object and LDS opt-in)
+    _w = io.collate([io.load_fsa_from_npz(f) for f in files[:2]], pad=synth.PAD)
+    LatticeBatch.from_dense_device(torch.from_numpy(_w[0]).to(dev), torch.from_numpy(_w[1]).to(dev)); torch.cuda.synchronize()
     for b0 in range(0, N, BATCH):
         t0 = time.perf_counter(); recs = [io.load_fsa_from_npz(f) for f in files[b0:b0 + BATCH]]; t["load"] += time.perf_counter() - t0
         t0 = time.perf_counter(); col = io.collate(recs, pad=synth.PAD); t["collate"] += time.perf_counter() - t0
         t0 = time.perf_counter(); lat = LatticeBatch.from_dense(col[0], col[1]); t["pack"] += time.perf_counter() - t0
         dt, _ = sync_time(lambda: ops.forward_backward(lat.to(dev), theta)); t["h2d+fb"] += dt
         dt, (em_d, tr_d) = sync_time(lambda: (torch.from_numpy(col[0]).to(dev), torch.from_numpy(col[1]).to(dev))); td["h2d_tables"] += dt
-        dt, lat_d = sync_time(lambda: LatticeBatch.from_dense(em_d, tr_d)); td["device_pack"] += dt
+        dt, lat_d = sync_time(lambda: LatticeBatch.from_dense_device(em_d, tr_d)); td["device_pack"] += dt
         dt, _ = sync_time(lambda: ops.forward_backward(lat_d, theta)); td["fb"] += dt
     out["dense_route_ms_per_example"] = {k: v / N * 1e3 for k, v in t.items()}
     out["dense_device_route_ms_per_example"] = {k: v / N * 1e3 for k, v in td.items()}
@@ -69,7 +72,9 @@ with tempfile.TemporaryDirectory() as d:
         for g in groups:
             LatticeBatch.concat(g, arena=arena)
         concat_ms = (time.perf_counter() - t0) / N * 1e3
-        dt, z = sync_time(lambda: [ops.forward_backward(b, theta).logz64.sum() for b in io.DevicePrefetcher(groups, dev)])
+        pf = io.DevicePrefetcher(groups, dev)
+        [None for _ in pf]  # (first pass: the staging arenas are allocated and page-locked)
+        dt, z = sync_time(lambda: [ops.forward_backward(b, theta).logz64.sum() for b in pf])
         out[f"sidecar_route_{tag}_ms_per_example"] = {"load": load_ms, "concat_into_pinned": concat_ms,
                                                      "prefetch_concat_h2d_fb_pipeline": dt / N * 1e3}
         out[f"sidecar_route_{tag}_examples_per_s_one_host_process"] = 1.0 / ((load_ms + dt / N * 1e3) * 1e-3)
