@@ -350,3 +350,47 @@ def test_random_dags_under_every_packing():
     ran = []
     check()
     assert sum(1 for x in ran if x > 0) >= 30 and max(ran) > 150
+
+
+def test_device_pack_layout_matches_host_packer():
+    """``nfst_pack_device_layout`` (the host half of the device packer: counts -> offsets, sizes, flags) reproduces the
+    host packer's meta records and header from the host packer's own counts."""
+    import ctypes as C
+    for lats in ([synth.layered_lattice(70 + i, n_states=40 + 31 * i, avg_degree=5.0, vocab=64, width=1 + i % 4, span=3) for i in range(6)],
+                 [synth.layered_lattice(80 + i, n_states=120, avg_degree=6.0, vocab=48, width=5, span=2, weighted=True) for i in range(3)],
+                 synth.bench_batch(2)):
+        for gm in (0, 1, 2):
+            ref = LatticeBatch.from_synth(lats, group_mode=gm)
+            B = ref.n_lattices
+            meta = ref.meta_host.copy()
+            for col in (_lib.META_ROW_OFF, _lib.META_ARC_OFF, _lib.META_FWD_OFF, _lib.META_BWD_OFF, _lib.META_FWD_SLOT_OFF, _lib.META_BWD_SLOT_OFF):
+                meta[:, col] = -1  # what the planning kernel leaves to the host
+            meta = np.ascontiguousarray(meta.reshape(-1))
+            status = np.zeros(B, np.int32)
+            scratch = np.full(B, ref.max_rows - int(ref.n_rows.max()), np.int32) if len(set(ref.n_rows)) == 1 else None
+            if scratch is None:  # scratch rows per lattice are not kept by the host packer: any split with the same maximum will do
+                scratch = np.zeros(B, np.int32)
+                scratch[int(np.argmax(ref.n_rows))] = ref.max_rows - int(ref.n_rows.max())
+            header = _lib.Batch()
+            bad = C.c_int32(-1)
+            rc = _lib.lib.nfst_pack_device_layout(meta.ctypes.data, status.ctypes.data, scratch.ctypes.data, B, ref.vocab, ref.weighted, C.byref(header), C.byref(bad))
+            assert rc == 0
+            assert np.array_equal(meta.reshape(B, -1), ref.meta_host)
+            for k in LatticeBatch._HEADER:
+                if k == "max_rows" and header.max_rows != ref._h[k]:
+                    assert header.max_rows >= int(ref.n_rows.max())  # (the split of the scratch rows above is a guess)
+                    continue
+                assert int(getattr(header, k)) == ref._h[k], k
+    # a failed lattice is reported with its code
+    status = np.array([0, -3, 0], np.int32)
+    rc = _lib.lib.nfst_pack_device_layout(np.zeros(48, np.int32).ctypes.data, status.ctypes.data, np.zeros(3, np.int32).ctypes.data, 3, 8, 0,
+                                          C.byref(_lib.Batch()), C.byref(bad))
+    assert rc == -3 and bad.value == 1
+
+
+def test_tuning_switches_are_checked():
+    assert _lib.lib.nfst_tuning_set(b"no such switch", 1) == -1
+    with _lib.tuning(tw=0, precise=1, neu_bf16=0):
+        pass
+    with pytest.raises(ValueError):
+        _lib.tuning(nonsense=1)
