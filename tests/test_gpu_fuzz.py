@@ -188,3 +188,34 @@ def test_fuzz_posterior_sampler(dev, seed):
                     ref = sc[p].sum() - o["logZ"]
                     worst_q = max(worst_q, abs(ref - logq[bb, k]) - 6e-8 * abs(ref))  # (beyond the float32 rounding of log q itself)
     assert _rec("fuzz_sampler_logq_beyond_f32_rounding", worst_q) <= 2e-5
+
+
+def test_precise_flavour_beyond_one_lattice_per_cu_and_through_autograd(dev):
+    """The float64-mantissa flavour with more lattices than CUs (it runs the tile-wave kernel whatever the batch size), with
+    the label histogram (d log Z / d theta), with per-arc scores through autograd, and as the source of the posterior
+    sampler's beta: all on 300-level chains."""
+    V = 40
+    lats = [synth.layered_lattice(700 + i, n_states=300 + (i % 7), avg_degree=2.5, vocab=V, width=1, span=1 + i % 2, max_degree=6) for i in range(300)]
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    assert int(lat.max_tiles) > 192 and lat.n_lattices > 256
+    theta = synth.label_scores(5, V, mean=-1.0, std=1.0)
+    th = torch.from_numpy(theta).to(dev).requires_grad_(True)
+    asc = (torch.randn(lat.total_arcs, device=dev) * 0.3).requires_grad_(True)
+    z = ops.log_z(lat, th, asc)
+    z.sum().backward()
+    r = ops.forward_backward(lat, th.detach(), arc_scores=asc.detach(), want_grad_theta=True)
+    assert torch.allclose(asc.grad, r.posterior, atol=1e-6)
+    assert torch.allclose(th.grad, r.grad_theta.sum(0), atol=1e-3, rtol=1e-5)
+    zz, post = r.logz64.cpu().numpy(), r.posterior.cpu().numpy()
+    a_np = asc.detach().cpu().numpy()
+    for b in range(0, 300, 23):
+        l = lats[b]
+        a0 = int(lat.arc_off[b])
+        o = O.forward_backward(l.n_rows, l.src, l.dst, theta[l.label].astype(np.float64) + a_np[a0:a0 + l.n_arcs])
+        assert _rec("precise_many_lattices_logz", abs(zz[b] - o["logZ"])) <= 1e-9
+        assert np.max(np.abs(post[a0:a0 + l.n_arcs] - o["posterior"])) <= 2e-6
+    with _lib.tuning(precise=0):
+        r32 = ops.forward_backward(lat, th.detach(), arc_scores=asc.detach())
+    assert float((r32.logz64 - r.logz64).abs().max()) <= 1e-4
+    s = ops.sample_paths(lat, th.detach(), 4, arc_scores=asc.detach(), seed=9)
+    assert int(s.lengths.min()) > 0 and bool(torch.isfinite(s.logq).all())

@@ -394,3 +394,36 @@ def test_tuning_switches_are_checked():
         pass
     with pytest.raises(ValueError):
         _lib.tuning(nonsense=1)
+
+
+def test_build_guard_on_register_reports():
+    """``nfst_amd.build.check_resources``: the build fails when a fused sweep does not own exactly the 32 AGPRs it stages tiles in,
+    when a sweep kernel spills vector registers, or when a kernel that stages nothing in AGPRs uses some (the round-2 abort:
+    DESIGN.md section 4.1); the report of the library that is loaded passes."""
+    import json
+    from nfst_amd import build
+    ok = {"k_forward_backward<512, 0, true, false, false>": dict(vgprs=62, agprs=32, vgpr_spill=0),
+          "k_forward_backward<1024, 0, false, true, false>": dict(vgprs=60, agprs=0, vgpr_spill=0),
+          "k_backward<512, 0, true, false>": dict(vgprs=67, agprs=0, vgpr_spill=0),
+          "k_backward_neural_grad<4>": dict(vgprs=128, agprs=0, vgpr_spill=9)}  # (not a sweep kernel: its spills are its own business)
+    assert build.check_resources(ok) == []
+    for name, patch in (("k_forward_backward<512, 0, true, false, false>", dict(agprs=40)),   # the compiler took AGPRs for itself
+                        ("k_forward_backward<512, 0, true, false, false>", dict(agprs=0)),
+                        ("k_forward_backward<512, 0, true, false, false>", dict(vgpr_spill=2)),
+                        ("k_forward_backward<1024, 0, false, true, false>", dict(vgpr_spill=1)),
+                        ("k_backward<512, 0, true, false>", dict(agprs=4))):
+        bad = {k: dict(v) for k, v in ok.items()}
+        bad[name].update(patch)
+        assert build.check_resources(bad), (name, patch)
+    # the remarks parser and the in-house demangler
+    text = ("x.h:1:1: remark: Function Name: _ZN12_GLOBAL__N_118k_forward_backwardILi256ELi0ELb1ELb0ELb0EEEv10nfst_batch [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.h:1:1: remark:     VGPRs: 60 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.h:1:1: remark:     AGPRs: 32 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.h:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    res = build.parse_resources(text)
+    names = build._demangle(list(res))
+    assert list(names.values()) == ["k_forward_backward<256, 0, true, false, false>"]
+    assert list(res.values())[0] == dict(vgprs=60, agprs=32, vgpr_spill=0)
+    rep = os.path.join(os.path.dirname(build.OUT), "libnfst_hip.resources.json")
+    if os.path.exists(rep):
+        assert build.check_resources(json.load(open(rep))) == []
