@@ -228,7 +228,7 @@ class Stepper:
         self.lat, self.theta, self.world, self.mode, self.fused = lat, theta, world, mode, fused
         self.arc_scores = arc_scores
         self.total = torch.zeros(3 * self.TRIPLES, dtype=torch.float64, device=dev)
-        self.out, self.i = None, 0
+        self.out, self.i, self.plans = None, 0, None
         self.pending = collections.deque()
 
     def slot_of(self, i):
@@ -238,15 +238,19 @@ class Stepper:
         from nfst_amd import ops
         j, slot = self.slot_of(self.i)
         self.i += 1
-        kw = dict(total=self.total[3 * j:3 * j + 3], total_slot=slot) if self.fused else {}
-        if self.mode == "fb":  # outputs are allocated by the first call and overwritten afterwards (steady state)
-            self.out = ops.forward_backward(self.lat, self.theta, arc_scores=self.arc_scores, want_alpha_beta=True,
-                                            want_posterior=True, out=self.out, **kw)
-        elif self.mode == "fb_sweeps_only":
-            self.out = ops.forward_backward(self.lat, self.theta, arc_scores=self.arc_scores, want_alpha_beta=False,
-                                            want_posterior=False, out=self.out, **kw)
-        else:
+        if self.mode == "bwd":
             return ops.backward(self.lat, self.theta, arc_scores=self.arc_scores, want_logbeta=False)
+        # the steady state of a training loop: same batch, same score tensors, outputs overwritten -- one prepared launch per
+        # slot triple (ops.ForwardBackwardLaunch: a ctypes call per step; the plain wrapper's ~40 us of host work per call is
+        # longer than the kernel and left the GPU idle between launches)
+        if self.plans is None:
+            full = self.mode == "fb"
+            self.plans = []
+            for t in range(self.TRIPLES if self.fused else 1):  # (every plan writes the same output tensors)
+                self.plans.append(ops.ForwardBackwardLaunch(self.lat, self.theta, arc_scores=self.arc_scores, want_alpha_beta=full,
+                                                            want_posterior=full, out=self.plans[0].out if self.plans else None,
+                                                            total=self.total[3 * t:3 * t + 3] if self.fused else None))
+        self.out = self.plans[j if self.fused else 0](slot if self.fused else 0)
         return self.out
 
     def reduce_loss(self, r):

@@ -827,6 +827,35 @@ def test_fused_log_z_total(dev):
     with pytest.raises(ValueError):
         ops.forward_backward(lat, theta, total=torch.zeros(3, device=dev))
 
+def test_prepared_launch_follows_in_place_updates_of_the_scores(dev):
+    """ops.ForwardBackwardLaunch: the host work of a step done once.  Every launch equals the wrapper's result on the scores
+    as they are at that moment (updated in place, as an optimiser does), fills the rotating loss slot, and a different
+    output set or a wrong `total` is refused as by the wrapper."""
+    lats = _mixed_batch()
+    lat = LatticeBatch.from_synth(lats, device=dev)
+    theta = torch.from_numpy(synth.label_scores(0, 64)).to(dev)
+    arc = torch.zeros(lat.total_arcs, device=dev)
+    total = torch.zeros(3, dtype=torch.float64, device=dev)
+    launch = ops.ForwardBackwardLaunch(lat, theta, arc_scores=arc, total=total)
+    for step in range(5):
+        theta.copy_(torch.from_numpy(synth.label_scores(step, 64)))
+        arc.copy_(0.1 * torch.randn(lat.total_arcs, generator=torch.Generator().manual_seed(step)))
+        got = launch(step % 3)
+        want = ops.forward_backward(lat, theta.clone(), arc_scores=arc.clone())
+        assert got is launch.out
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+        t = total.cpu().numpy()
+        assert abs(t[step % 3] - float(want.logz64.sum())) <= 1e-9 * max(1.0, abs(float(want.logz64.sum())))
+        assert t[(step + 1) % 3] == 0.0
+    with pytest.raises(ValueError):
+        ops.ForwardBackwardLaunch(lat, theta, total=torch.zeros(3, device=dev))
+    with pytest.raises(ValueError):
+        ops.ForwardBackwardLaunch(lat, theta, want_posterior=False, out=launch.out)
+
+
 def test_snips_shaped_batch(dev):
     """BASELINE configs[2]: a batch of 64 tagging-shaped lattices (S ~ 400..1500, V ~ 250, long and
     narrow: a few tag states per token position, up to ~750 positions)."""
