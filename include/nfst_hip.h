@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define NFST_ABI_VERSION 6
+#define NFST_ABI_VERSION 7
 
 /* error codes */
 #define NFST_OK 0
@@ -145,7 +145,80 @@ typedef struct nfst_batch {
   const int32_t *bwd_perm;   /* [bwd_slots] */
   const uint32_t *arc_sd;    /* [total_arcs + 8] src | dst << 16: the canonical arcs in 6 B/arc */
   const uint16_t *arc_l16;   /* [total_arcs + 8] label            for the posterior pass        */
+  /* ABI 7 */
+  const struct nfst_chunks *chunks; /* HOST pointer or NULL: the chunked programs of a batch of deep, narrow lattices
+                                       (nfst_pack_chunks) with their device arrays and scratch; nfst_backward and
+                                       nfst_forward_backward run the chunked flavour when it is there */
+  const int32_t *only;       /* launcher-internal, callers pass NULL: device [n_lattices]; a sweep kernel skips lattice b */
+  int32_t only_tag;          /*   unless only[b] == only_tag (the chunked flavour hands lattices whose numbers leave   */
+  int32_t reserved2;         /*   its range back to the general kernels this way)                                      */
 } nfst_batch;
+
+/*
+ * Chunked programs for deep, narrow lattices (SNIPS-shaped tagging machines, main_snips.py / lstm_snips.yaml:2
+ * max_length 750: hundreds of levels of a few states each, where a level-by-level sweep is a chain of ~200 ns steps
+ * with most of a wave idle).  Per lattice and direction the states are put in topological order ("positions":
+ * by longest path from the start for alpha, to the sink for beta) and the positions are cut into C chunks.  A chunk's
+ * values depend on at most F positions before it (its frontier; arcs reach at most R - 1 positions back), so
+ *   pass 1  every chunk is swept at the same time with F right-hand sides (unit vectors on its frontier), one lane per
+ *           (chunk, right-hand side): T[p][f] = total weight of the paths from frontier state f to position p inside the chunk;
+ *   pass 2  the frontier values are chained through the chunks (C steps of an F x F product);
+ *   pass 3  value[p] = sum_f T[p][f] * frontier[f] for every position, all at once.
+ * Depth L becomes L / C + C.  Pass 1 computes in plain float64 (a chunk's products stay within 2^+-480 for any
+ * sane scores); passes 2 and 3 in (float64 mantissa, int32 exponent).  A lattice whose numbers leave that range
+ * (a weight or a partial sum beyond 2^+-480) is flagged on the device and run by the general kernels in the same call.
+ * Results: the same function as the general kernels (<= 1e-9 from the float64 oracle on log Z).
+ */
+#define NFST_CHK_META_WORDS 8
+#define NFST_CHK_C 0          /* chunks */
+#define NFST_CHK_F 1          /* right-hand sides per chunk (largest frontier) */
+#define NFST_CHK_R 2          /* ring slots (power of two > the longest reach of an arc, in positions; >= F) */
+#define NFST_CHK_NPOS 3       /* positions = reachable states; position 0 is the start (alpha) / the sink (beta) */
+#define NFST_CHK_TAB_OFF 4    /* first chunk of this program in tab (4 int32 per chunk) */
+#define NFST_CHK_STREAM_OFF 5 /* first entry of this program in stream */
+#define NFST_CHK_POS_OFF 6    /* first position of this program in pos */
+#define NFST_CHK_T_OFF 7      /* first row of this program's T matrix, in units of 64 doubles */
+/* stream entry: operand ring slot (bits 0..5) | last entry of its state (bit 6) | weight zero (bit 7: the entry
+ * of a state without arcs) | canonical arc, relative to the lattice (bits 8..31) */
+#define NFST_CHK_LAST 0x40u
+#define NFST_CHK_ZERO 0x80u
+
+typedef struct nfst_chunks {
+  int32_t n_lattices;
+  int32_t threads;         /* workgroup size the programs were cut for: C * F <= threads for every program */
+  int32_t lds_bytes;       /* dynamic LDS of the sweep kernel */
+  int32_t launches;        /* launcher-internal: counts the launches (tags the device flags) */
+  int64_t n_tab;           /* chunks over all programs */
+  int64_t n_stream;        /* stream entries over all programs */
+  int64_t n_pos;           /* positions over all programs */
+  int64_t t_units;         /* T rows over all programs, in units of 64 doubles */
+  int64_t total_rows;      /* of the batch the programs were cut from */
+  int64_t total_arcs;
+  const int32_t *meta;     /* [n_lattices * 2 * NFST_CHK_META_WORDS]: direction 0 = alpha, 1 = beta */
+  const int32_t *tab;      /* [n_tab * 4]: first position, first entry (relative to the program), entries, 0 */
+  const uint32_t *stream;  /* [n_stream] */
+  const int32_t *pos;      /* [n_pos] position -> state */
+  void *ws;                /* device scratch of nfst_chunks_ws_bytes() bytes, owned by the caller and zeroed by it once (when
+                              `launches` is zero), used by every launch on this batch (one launch at a time per batch) */
+  int64_t ws_bytes;
+} nfst_chunks;
+
+typedef struct nfst_chunk_opts {
+  int32_t threads;         /* 0 = by batch size: 1024 when every program gets a CU to itself, else 512 */
+  int32_t lds_bytes;       /* 0 = by batch size: 128 KiB / 64 KiB */
+  int32_t force;           /* 1 = cut every batch that can be cut (testing); 0 = only when the cost model of the
+                              two flavours says the chunked one is faster */
+  int32_t max_chunks;      /* 0 = no limit beside threads / LDS (testing: small values) */
+} nfst_chunk_opts;
+
+typedef struct nfst_chunks_host nfst_chunks_host; /* opaque, owns host arrays */
+/* Cut the chunked programs of a packed batch (host arrays, as nfst_packed_view returns them).  *out = NULL (and
+ * NFST_OK) when the batch is not one for this flavour: an arc that reaches more than 63 positions back, a frontier
+ * too wide for the workgroup, or no gain by the cost model. */
+int nfst_pack_chunks(const nfst_batch *host_batch, const nfst_chunk_opts *opts, nfst_chunks_host **out);
+int nfst_chunks_view(const nfst_chunks_host *c, nfst_chunks *view); /* host pointers; ws = NULL */
+void nfst_chunks_free(nfst_chunks_host *c);
+int64_t nfst_chunks_ws_bytes(const nfst_chunks *c);
 
 const char *nfst_strerror(int code);
 int nfst_abi_version(void);
@@ -306,6 +379,7 @@ typedef struct nfst_scores {
  */
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta,
                   double *logz64, float *logz32, float *beta_me, void *stream);
+/* (lat->chunks != NULL and beta_me == NULL: the chunked flavour, see nfst_chunks) */
 
 /*
  * Full forward-backward: alpha and beta sweeps, log Z and arc posteriors

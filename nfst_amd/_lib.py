@@ -19,6 +19,8 @@ if os.environ.get("NFST_TUNING") == "1" and os.environ.get("NFST_LIB"):
     LIB_PATH = os.environ["NFST_LIB"]
 
 META_WORDS = 16
+CHK_META_WORDS = 8
+CHK_C, CHK_F, CHK_R, CHK_NPOS, CHK_TAB_OFF, CHK_STREAM_OFF, CHK_POS_OFF, CHK_T_OFF = range(8)
 (META_ROW_OFF, META_N_ROWS, META_ARC_OFF, META_N_ARCS, META_FWD_OFF, META_FWD_TILES, META_BWD_OFF,
  META_BWD_TILES, META_SINK, META_N_REACH, META_DEPTH, META_N_DP, META_FWD_U, META_BWD_U, META_FWD_SLOT_OFF,
  META_BWD_SLOT_OFF) = range(16)
@@ -46,7 +48,22 @@ class Batch(C.Structure):
         ("meta", C.c_void_p), ("row_ptr", C.c_void_p), ("arc_src", C.c_void_p), ("arc_dst", C.c_void_p),
         ("arc_label", C.c_void_p), ("arc_w", C.c_void_p), ("fwd_stream", C.c_void_p), ("bwd_stream", C.c_void_p),
         ("fwd_perm", C.c_void_p), ("bwd_perm", C.c_void_p), ("arc_sd", C.c_void_p), ("arc_l16", C.c_void_p),
+        ("chunks", C.c_void_p), ("only", C.c_void_p), ("only_tag", C.c_int32), ("reserved2", C.c_int32),
     ]
+
+
+class Chunks(C.Structure):  # nfst_chunks: the chunked programs of a batch of deep, narrow lattices
+    _fields_ = [
+        ("n_lattices", C.c_int32), ("threads", C.c_int32), ("lds_bytes", C.c_int32), ("launches", C.c_int32),
+        ("n_tab", C.c_int64), ("n_stream", C.c_int64), ("n_pos", C.c_int64), ("t_units", C.c_int64),
+        ("total_rows", C.c_int64), ("total_arcs", C.c_int64),
+        ("meta", C.c_void_p), ("tab", C.c_void_p), ("stream", C.c_void_p), ("pos", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+    ]
+
+
+class ChunkOpts(C.Structure):
+    _fields_ = [("threads", C.c_int32), ("lds_bytes", C.c_int32), ("force", C.c_int32), ("max_chunks", C.c_int32)]
 
 
 class Scores(C.Structure):
@@ -100,6 +117,10 @@ def _load():
         "nfst_concat_sizes": (C.c_int, [BP, i32, BP]),
         "nfst_concat_packed": (C.c_int, [BP, i32, BP, i32]),
         "nfst_packed_free": (None, [vp]),
+        "nfst_pack_chunks": (C.c_int, [BP, C.POINTER(ChunkOpts), C.POINTER(vp)]),
+        "nfst_chunks_view": (C.c_int, [vp, C.POINTER(Chunks)]),
+        "nfst_chunks_free": (None, [vp]),
+        "nfst_chunks_ws_bytes": (i64, [C.POINTER(Chunks)]),
         "nfst_lds_bytes": (i64, [BP]),
         "nfst_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp]),
         "nfst_forward_backward": (C.c_int, [BP, SP, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]),
@@ -150,7 +171,7 @@ def check(code: int, where: str, lattice: int = -1) -> None:
 class tuning:
     """``with tuning(tw=0, precise=0): ...`` -- launcher switches for tests and A/B measurements
     (``nfst_tuning_set``, include/nfst_hip.h); the defaults come back on exit."""
-    DEFAULTS = dict(tw=1, fused=1, xcache=1, precise=-1, neu_pack=1, neu_small=1, neu_bf16=1)
+    DEFAULTS = dict(tw=1, fused=1, xcache=1, precise=-1, neu_pack=1, neu_small=1, neu_bf16=1, chunked=1)
 
     def __init__(self, **kw):
         unknown = set(kw) - set(self.DEFAULTS)

@@ -1,7 +1,7 @@
 """Builds the HIP library in-tree: ``python -m nfst_amd.build``.
 
-One ``hipcc --offload-arch=gfx950`` command over ``csrc/pack.cpp`` (host
-scheduler) and ``csrc/kernels.hip`` (C-ABI launchers; the kernels are in the
+One ``hipcc --offload-arch=gfx950`` command over ``csrc/pack.cpp``, ``csrc/chunk_pack.cpp`` (host
+schedulers) and ``csrc/kernels.hip`` (C-ABI launchers; the kernels are in the
 headers it includes: semiring, tile pipeline, forward-backward, path kernels) ->
 ``nfst_amd/lib/libnfst_hip.so``.  hipcc cross-compiles without a GPU.
 
@@ -18,7 +18,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SRC = [os.path.join(CSRC, "pack.cpp"), os.path.join(CSRC, "kernels.hip")]
+SRC = [os.path.join(CSRC, "pack.cpp"), os.path.join(CSRC, "chunk_pack.cpp"), os.path.join(CSRC, "kernels.hip")]
 HDR = os.path.join(ROOT, "include", "nfst_hip.h")
 OUT = os.path.join(HERE, "lib", "libnfst_hip.so")
 

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NT) void k_backward(nfst_batch lat, nfst_scores sc,
   extern __shared__ float2 lds_raw[];
   VT *lds = reinterpret_cast<VT *>(lds_raw);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (lat.only && lat.only[b] != lat.only_tag) return;  // (the chunked flavour ran this lattice: nfst_batch.only)
   // this thread's label score: requested before anything waits for the meta record
   const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;
   const Meta m = load_meta(lat.meta, b);
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(NT) void k_forward_backward(
   VT *lds = reinterpret_cast<VT *>(lds_raw);
   constexpr int kTwSlot = PREC ? kSlotWordsP : kSlotWords2;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (lat.only && lat.only[b] != lat.only_tag) return;  // (the chunked flavour ran this lattice: nfst_batch.only)
   if (tid == 0) NFST_STAMP(0);
   // this thread's label score: requested before anything waits for the meta record
   const float theta_first = tid < lat.vocab ? sc.theta[(size_t)sc.theta_stride * b + tid] : 0.0f;

@@ -10,6 +10,7 @@
 // beta sweep (neural_kernels.h) has one dense product per state and runs it on float32 MFMA.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
@@ -29,6 +30,7 @@ namespace {
 #include "path_kernels.h"
 #include "neural_kernels.h"
 #include "pack_kernels.h"
+#include "chunk_kernels.h"
 
 // ------------------------------------------------------------------ host helpers
 int check_batch(const nfst_batch *lat) {
@@ -105,6 +107,7 @@ struct Tuning {
   int neu_pack = 1;         // NFST_NEU_PACK=0: phase B reads Wh from the matrix itself
   int neu_bf16 = 1;         // NFST_NEU_BF16=0: phase B on float32 MFMAs instead of three bfloat16 parts (hid a multiple of 64)
   int neu_small = 1;        // NFST_NEU_NO_SMALL=1: two-phase neural kernels for every hidden size
+  int chunked = 1;          // NFST_CHUNKED=0: never the chunked flavour (a batch with chunked programs runs the general kernels)
 };
 Tuning &tuning() {
   static Tuning t = [] {
@@ -119,6 +122,7 @@ Tuning &tuning() {
     r.neu_pack = num("NFST_NEU_PACK", 1) != 0;
     r.neu_bf16 = num("NFST_NEU_BF16", 1) != 0;
     r.neu_small = getenv("NFST_NEU_NO_SMALL") ? 0 : 1;
+    r.chunked = num("NFST_CHUNKED", 1) != 0;
     return r;
   }();
   return t;
@@ -134,6 +138,35 @@ int precise_ring(const nfst_batch *lat, int64_t fixed, int n_rings) {
   const int64_t r = (kMaxLds - lds_reserve() - fixed) / ((int64_t)kSlotWordsP * 4 * n_rings);
   const int R = (int)(r > kMaxRing ? kMaxRing : r) & ~3;
   return R >= 4 ? R : 0;
+}
+
+
+// The chunked flavour (chunk_kernels.h): sweeps (one workgroup per lattice and direction), then posteriors / totals.  Returns
+// the device flags of the lattices that have to be run again by the general kernels (tagged *tag).
+int chunked_launch(const nfst_batch *lat, const nfst_scores *scores, int n_dirs, float *logalpha, float *logbeta, double *logz64,
+                   float *logz32, float *posterior, float *grad_theta, double *logz_total, int total_slot, hipStream_t st,
+                   const int32_t **flags, int *tag) {
+  nfst_chunks *ck = const_cast<nfst_chunks *>(lat->chunks);
+  if (ck->n_lattices != lat->n_lattices || ck->total_rows != lat->total_rows || ck->total_arcs != lat->total_arcs || !ck->meta ||
+      !ck->tab || !ck->stream || !ck->pos || !ck->ws || ck->ws_bytes < nfst_chunks_ws_bytes(ck) || ck->threads < 64 ||
+      ck->threads > 1024 || (ck->threads & 63) || ck->lds_bytes <= 0 || ck->lds_bytes > kMaxLds || ((uintptr_t)ck->ws & 15))
+    return NFST_ERR_ARG;
+  ck->launches = ck->launches >= INT_MAX - 1 ? 1 : ck->launches + 1;
+  *tag = ck->launches;
+  *flags = chk_ws(*ck).flags;
+  int rc;
+  if ((rc = set_lds(k_chunk_sweep, ck->lds_bytes))) return rc;
+  hipLaunchKernelGGL(k_chunk_sweep, dim3(lat->n_lattices * n_dirs), dim3(ck->threads), (size_t)ck->lds_bytes, st, *lat, *scores, *ck,
+                     *tag, n_dirs, logalpha, logbeta, logz64, logz32, grad_theta);
+  if (n_dirs == 2 && (posterior || grad_theta || logz_total)) {
+    const size_t lds = grad_theta ? (size_t)lat->vocab * 4 : 0;
+    // workgroups of 256 threads, about four arcs per thread of the largest lattice: a slice of a lattice's arcs each
+    const int64_t max_arcs = ((int64_t)lat->reserved0 >> NFST_BATCH_MAX_ARCS_SHIFT) & NFST_BATCH_MAX_ARCS_CAP;
+    const int parts = (posterior || grad_theta) ? (int)std::max<int64_t>(1, std::min<int64_t>(64, (max_arcs + 1023) / 1024)) : 1;
+    hipLaunchKernelGGL(k_chunk_post, dim3(lat->n_lattices * parts), dim3(256), lds, st, *lat, *scores, *ck, *tag, parts, posterior,
+                       grad_theta, logz_total, total_slot);
+  }
+  return hip_status(hipGetLastError());
 }
 
 }  // namespace
@@ -157,6 +190,7 @@ int nfst_tuning_set(const char *name, int value) {
   else if (n == "neu_pack") t.neu_pack = value != 0;
   else if (n == "neu_bf16") t.neu_bf16 = value != 0;
   else if (n == "neu_small") t.neu_small = value != 0;
+  else if (n == "chunked") t.chunked = value != 0;
   else if (n == "lds_reserve_kb") t.lds_reserve = (value > 0 && value <= 96) ? (int64_t)value * 1024 : 0;
   else return NFST_ERR_ARG;
   return NFST_OK;
@@ -290,6 +324,16 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
+  if (lat->chunks && tuning().chunked && !beta_me) {
+    // deep, narrow lattices: the chunked sweeps; lattices whose numbers leave their range are flagged on the device and
+    // run by the general kernels below (a launch that finds no flag set returns at once)
+    nfst_batch rest = *lat;
+    rest.chunks = nullptr;
+    if ((rc = chunked_launch(lat, scores, 1, nullptr, logbeta, logz64, logz32, nullptr, nullptr, nullptr, 0, (hipStream_t)stream,
+                             &rest.only, &rest.only_tag)))
+      return rc;
+    return nfst_backward(&rest, scores, logbeta, logz64, logz32, nullptr, stream);
+  }
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
   RingCfg cfg;
@@ -348,6 +392,15 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
   if (logz_total && (total_slot < 0 || total_slot > 2)) return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
+  if (lat->chunks && tuning().chunked && !beta_me) {  // (as in nfst_backward)
+    nfst_batch rest = *lat;
+    rest.chunks = nullptr;
+    if ((rc = chunked_launch(lat, scores, 2, logalpha, logbeta, logz64, logz32, posterior, grad_theta, logz_total, (int)total_slot,
+                             (hipStream_t)stream, &rest.only, &rest.only_tag)))
+      return rc;
+    return nfst_forward_backward(&rest, scores, logalpha, logbeta, logz64, logz32, posterior, grad_theta, nullptr, logz_total, total_slot,
+                                 stream);
+  }
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const bool both = lat->weighted && lat->arc_w && scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);

@@ -45,6 +45,80 @@ def _view(ptr, n, ctype, dtype) -> np.ndarray:
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype, copy=True)
 
 
+class ChunkProgram:
+    """The chunked programs of a batch of deep, narrow lattices (``nfst_chunks``, include/nfst_hip.h): per lattice and
+    direction the states in topological order, cut into chunks that are swept at the same time.  Built on the host by
+    ``LatticeBatch.build_chunks`` (or by ``LatticeBatch.to`` when the cost model says the batch is one for this flavour);
+    the device copy owns the scratch every launch on the batch uses (one launch at a time per batch)."""
+    _FIELDS = ("meta", "tab", "stream", "pos")
+    _HEADER = ("n_lattices", "threads", "lds_bytes", "n_tab", "n_stream", "n_pos", "t_units", "total_rows", "total_arcs")
+
+    def __init__(self, header: dict, tensors: dict):
+        self._h, self._t = dict(header), dict(tensors)
+        self.meta_host = self._t["meta"].detach().cpu().numpy().reshape(-1, 2, _lib.CHK_META_WORDS).copy()
+        self.ws = None
+        self._struct = None
+
+    @classmethod
+    def build(cls, lat: "LatticeBatch", threads: int = 0, lds_bytes: int = 0, force: bool = False,
+              max_chunks: int = 0) -> "Optional[ChunkProgram]":
+        if lat.device.type != "cpu":
+            raise ValueError("chunked programs are cut from the host copy of a batch")
+        opts = _lib.ChunkOpts(int(threads), int(lds_bytes), 1 if force else 0, int(max_chunks))
+        handle = C.c_void_p()
+        check(lib.nfst_pack_chunks(C.byref(lat.c_struct()), C.byref(opts), C.byref(handle)), "nfst_pack_chunks")
+        if not handle:
+            return None  # not a batch for this flavour
+        try:
+            v = _lib.Chunks()
+            check(lib.nfst_chunks_view(handle, C.byref(v)), "nfst_chunks_view")
+            arrs = {"meta": _view(v.meta, v.n_lattices * 2 * _lib.CHK_META_WORDS, C.c_int32, np.int32),
+                    "tab": _view(v.tab, v.n_tab * 4, C.c_int32, np.int32),
+                    "stream": _view(v.stream, v.n_stream, C.c_int32, np.int32),
+                    "pos": _view(v.pos, v.n_pos, C.c_int32, np.int32)}
+            header = {k: int(getattr(v, k)) for k in cls._HEADER}
+        finally:
+            lib.nfst_chunks_free(handle)
+        return cls(header, {k: torch.from_numpy(a) for k, a in arrs.items()})
+
+    def to(self, device, non_blocking: bool = False) -> "ChunkProgram":
+        device = torch.device(device)
+        out = ChunkProgram.__new__(ChunkProgram)
+        out._h, out.meta_host, out._struct, out.ws = dict(self._h), self.meta_host, None, None
+        out._t = {k: v.to(device, non_blocking=non_blocking) for k, v in self._t.items()}
+        if device.type == "cuda":
+            # (zeroed once: the flags at its end are compared with the launch counter, which starts at one)
+            out.ws = torch.zeros(int(lib.nfst_chunks_ws_bytes(C.byref(out.c_struct()))), dtype=torch.uint8, device=device)
+            out._struct = None
+        return out
+
+    def pin_memory(self) -> "ChunkProgram":
+        out = ChunkProgram.__new__(ChunkProgram)
+        out._h, out.meta_host, out._struct, out.ws = dict(self._h), self.meta_host, None, None
+        out._t = {k: v.pin_memory() for k, v in self._t.items()}
+        return out
+
+    def flagged(self) -> np.ndarray:
+        """[B] bool: lattices the last launch handed back to the general kernels (numbers beyond the float64 range of
+        pass 1).  Synchronises; for tests and diagnostics."""
+        h = self._h
+        off = h["n_stream"] * 16 + h["t_units"] * 512 + h["total_rows"] * 32 + h["n_lattices"] * 16
+        flags = self.ws[off:off + 4 * h["n_lattices"]].cpu().numpy().view(np.int32)
+        return flags == int(self.c_struct().launches)
+
+    def c_struct(self) -> _lib.Chunks:
+        if self._struct is None:
+            s = _lib.Chunks()
+            for k, v in self._h.items():
+                setattr(s, k, v)
+            for k in self._FIELDS:
+                setattr(s, k, self._t[k].data_ptr())
+            if self.ws is not None:
+                s.ws, s.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+            self._struct = s
+        return self._struct
+
+
 class LatticeBatch:
     """Packed lattices.  Tensors live on ``self.device``; ``meta`` is also kept on
     the host (numpy) because shapes and offsets are needed to size outputs."""
@@ -59,6 +133,8 @@ class LatticeBatch:
         self._t = dict(tensors)
         self.meta_host = self._t["meta"].detach().cpu().numpy().reshape(-1, _lib.META_WORDS).copy()
         self._struct = None
+        self.chunks = None          # ChunkProgram of a batch of deep, narrow lattices (build_chunks / to)
+        self._chunks_tried = False
 
     # ---------------------------------------------------------------- construction
     @staticmethod
@@ -208,6 +284,7 @@ class LatticeBatch:
                                         C.byref(header), stream), "nfst_pack_device_emit")
         out = cls.__new__(cls)
         out._h, out._t, out._struct = h, tensors, None
+        out.chunks, out._chunks_tried = None, True  # (packed on the device: the general kernels)
         out.meta_host = meta_h.reshape(-1, _lib.META_WORDS).copy()
         out._keep = (ws, src_d, label_d, dst_d, w_d, small, n_rows_d, plan)  # alive until the emit launch has run
         return out
@@ -399,19 +476,37 @@ class LatticeBatch:
         return out.to(device) if device is not None else out
 
     # ---------------------------------------------------------------- placement
-    def to(self, device, non_blocking: bool = False) -> "LatticeBatch":
+    def to(self, device, non_blocking: bool = False, auto_chunks: bool = True) -> "LatticeBatch":
         device = torch.device(device)
         t = {k: (None if v is None else v.to(device, non_blocking=non_blocking)) for k, v in self._t.items()}
         out = LatticeBatch.__new__(LatticeBatch)
         out._h, out._t, out._struct = dict(self._h), t, None
         out.meta_host = self.meta_host  # shapes and offsets stay on the host: no device round trip
+        # deep, narrow lattices: the chunked programs are cut on the way to the device (once per host batch; a quick no
+        # for every other shape) and travel with the batch
+        if device.type == "cuda" and self.device.type == "cpu" and not self.__dict__.get("_chunks_tried", False) and auto_chunks:
+            self.build_chunks()
+        ck = self.__dict__.get("chunks")
+        out.chunks = None if ck is None else ck.to(device, non_blocking=non_blocking)
+        out._chunks_tried = self.__dict__.get("_chunks_tried", False)
         return out
+
+    def build_chunks(self, force: bool = False, **opts) -> bool:
+        """Cut the chunked programs of this (host) batch: ``nfst_pack_chunks``.  Without ``force`` only when the cost model
+        of the two flavours says the chunked sweeps are faster (deep, narrow lattices); True when the batch has them now."""
+        self.chunks = ChunkProgram.build(self, force=force, **opts)
+        self._chunks_tried = True
+        self._struct = None
+        return self.chunks is not None
 
     def pin_memory(self) -> "LatticeBatch":
         """Page-locked host copy: what ``to(device, non_blocking=True)`` needs to be asynchronous."""
         t = {k: (None if v is None else v.pin_memory()) for k, v in self._t.items()}
         out = LatticeBatch.__new__(LatticeBatch)
         out._h, out._t, out._struct, out.meta_host = dict(self._h), t, None, self.meta_host
+        ck = self.__dict__.get("chunks")
+        out.chunks = None if ck is None else ck.pin_memory()
+        out._chunks_tried = self.__dict__.get("_chunks_tried", False)
         return out
 
     @property
@@ -420,7 +515,7 @@ class LatticeBatch:
 
     # ---------------------------------------------------------------- accessors
     def __getattr__(self, name):
-        if name in ("_h", "_t"):
+        if name in ("_h", "_t", "chunks", "_chunks_tried"):
             raise AttributeError(name)
         if name in self._h:
             return self._h[name]
@@ -481,6 +576,9 @@ class LatticeBatch:
             for k in self._FIELDS:
                 t = self._t[k]
                 setattr(s, k, None if t is None or t.numel() == 0 else t.data_ptr())
+            ck = self.__dict__.get("chunks")
+            if ck is not None and ck.ws is not None:
+                s.chunks = C.addressof(ck.c_struct())
             self._struct = s
         return self._struct
 
