@@ -492,9 +492,13 @@ class LatticeBatch:
         return out
 
     def build_chunks(self, force: bool = False, **opts) -> bool:
-        """Cut the chunked programs of this (host) batch: ``nfst_pack_chunks``.  Without ``force`` only when the cost model
+        """Cut the chunked programs of this batch: ``nfst_pack_chunks`` (host work, on the canonical arrays).  Without ``force`` only when the cost model
         of the two flavours says the chunked sweeps are faster (deep, narrow lattices); True when the batch has them now."""
-        self.chunks = ChunkProgram.build(self, force=force, **opts)
+        if self.device.type == "cuda":  # (packed on the device, or moved there without programs: cut from a host copy)
+            ck = ChunkProgram.build(self.to("cpu", auto_chunks=False), force=force, **opts)
+            self.chunks = None if ck is None else ck.to(self.device)
+        else:
+            self.chunks = ChunkProgram.build(self, force=force, **opts)
         self._chunks_tried = True
         self._struct = None
         return self.chunks is not None

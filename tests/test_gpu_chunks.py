@@ -135,3 +135,51 @@ def test_log_z_autograd_through_the_chunked_flavour(dev):
         ops.log_z(lat, theta2, asc2).sum().backward()
     assert torch.max(torch.abs(asc.grad - asc2.grad)).item() <= 2e-6
     assert torch.max(torch.abs(theta.grad - theta2.grad)).item() <= 1e-3 * max(1.0, float(theta2.grad.abs().max()))
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzz_chunked_flavour_against_oracle(dev, seed):
+    """random narrow lattices (chains to eight states per level, arcs up to three levels ahead), random cuts (workgroup size, LDS
+    budget, chunk limit), per-lattice theta, table weights and caller scores: log Z within 1e-8 of the float64 oracle, posteriors
+    within 2e-6, for every lattice the chunked kernels kept"""
+    rng = np.random.default_rng(9000 + seed)
+    B = int(rng.integers(1, 20))
+    V = int(rng.choice([24, 64, 300]))
+    weighted = bool(rng.integers(0, 2))
+    lats = []
+    while len(lats) < B:
+        try:
+            lats.append(synth.layered_lattice(int(rng.integers(1, 1 << 30)), n_states=int(rng.choice([4, 6, 11, 40, 150, 600, 1500])),
+                                              avg_degree=float(rng.choice([1.5, 3.0, 5.0])), vocab=V, width=int(rng.choice([1, 2, 3, 4, 6, 8])),
+                                              span=int(rng.choice([1, 2, 3])), max_degree=min(10, (V - 12) // 2), weighted=weighted))
+        except AssertionError:
+            continue
+    host = LatticeBatch.from_synth(lats)
+    opts = dict(threads=int(rng.choice([64, 256, 512, 1024])), max_chunks=int(rng.choice([0, 0, 1, 2, 7])),
+                lds_bytes=int(rng.choice([0, 16384, 65536])))
+    if not host.build_chunks(force=True, **opts):
+        pytest.skip("no cut within these limits")
+    lat = host.to(dev)
+    thetas = np.stack([synth.label_scores(int(rng.integers(1 << 20)), V, mean=float(rng.choice([-2.0, 0.0, 1.0])), std=float(rng.choice([0.3, 1.0])))
+                       for _ in range(B)])
+    asc = (0.5 * rng.standard_normal(lat.total_arcs)).astype(np.float32) if rng.integers(0, 2) else None
+    r = ops.forward_backward(lat, torch.from_numpy(thetas), arc_scores=None if asc is None else torch.from_numpy(asc))
+    fl = lat.chunks.flagged()
+    _check(lat, lats, r, None, asc=asc, thetas=thetas, loose=tuple(np.flatnonzero(fl).tolist()))
+    b = ops.backward(lat, torch.from_numpy(thetas), arc_scores=None if asc is None else torch.from_numpy(asc))
+    assert torch.max(torch.abs(b.logz64 - r.logz64)).item() <= 2e-5
+
+
+def test_chunked_programs_for_a_batch_packed_on_the_device(dev):
+    """build_chunks on a device batch cuts the programs from a host copy of its canonical arrays"""
+    lats = synth.snips_shaped_batch(6, vocab=64, first_seed=5200)
+    n_rows, arc_off, src, label, dst, w = synth.batch_arcs(lats)
+    lat = LatticeBatch.from_arcs_device(n_rows, arc_off, src, label, dst, 64, device=dev)
+    assert lat.chunks is None
+    theta = torch.from_numpy(synth.label_scores(2, 64, mean=-1.0, std=0.5))
+    g = ops.forward_backward(lat, theta)
+    assert lat.build_chunks(force=True) and lat.chunks.ws is not None
+    r = ops.forward_backward(lat, theta)
+    assert not lat.chunks.flagged().any()
+    assert torch.max(torch.abs(r.logz64 - g.logz64)).item() <= 1e-7 and torch.max(torch.abs(r.posterior - g.posterior)).item() <= 2e-6
+    _check(lat, lats, r, synth.label_scores(2, 64, mean=-1.0, std=0.5))
