@@ -413,6 +413,13 @@ def aux_single_gpu(dev, theta256, steps):
     lat = LatticeBatch.from_synth(lats, device=dev)
     aux["configs2_snips_shaped_b64"] = fb_line(lat, th)
     aux["configs2_snips_shaped_b64"]["viterbi_ms"] = time_op(lambda: ops.viterbi(lat, th), iters)
+    # (deep and narrow: the packer cut chunked programs on the way to the device; the general kernels on the same batch beside it)
+    from nfst_amd import _lib
+    aux["configs2_snips_shaped_b64"]["flavour"] = "chunked" if lat.chunks is not None else "general"
+    aux["configs2_snips_shaped_b64"]["beta_only_ms"] = time_op(lambda: ops.backward(lat, th, want_logbeta=False), iters)
+    with _lib.tuning(chunked=0):
+        aux["configs2_snips_shaped_b64"]["general_kernels_ms_per_step"] = fb_line(lat, th)["ms_per_step"]
+        aux["configs2_snips_shaped_b64"]["general_kernels_beta_only_ms"] = time_op(lambda: ops.backward(lat, th, want_logbeta=False), iters)
     # batch size 1: the reference's decoder scores one lattice at a time (src/decode/decoder.py:77-79)
     one = LatticeBatch.from_synth(lats[:1], device=dev)
     aux["decode_b1_snips_shaped"] = dict(fb_line(one, th), viterbi_ms=time_op(lambda: ops.viterbi(one, th), iters))
