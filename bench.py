@@ -664,7 +664,7 @@ def main():
                                       ("one resident batch, ~%.0f MB touched per launch" % (touched / 1e6)),
                        "max_depth": int(lat.depth.max()), "max_tiles": int(lat.max_tiles), "loss": -float(loss.item()),
                        "host_pack_s": pack_s,
-                       "launch": "hip_graph_replay" if args.graph else "python",
+                       "launch": "hip_graph_replay" if args.graph else "prepared launch (ops.ForwardBackwardLaunch: one ctypes call per step)",
                        "loss_reduction": "fused in the kernel (atomic adds)" if fused else "torch.sum",
                        "lds_reserve_kb": int(os.environ.get("NFST_LDS_RESERVE_KB", "0") or 0),
                        "aux": aux},

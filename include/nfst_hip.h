@@ -168,6 +168,8 @@ typedef struct nfst_batch {
  * sane scores); passes 2 and 3 in (float64 mantissa, int32 exponent).  A lattice whose numbers leave that range
  * (a weight or a partial sum beyond 2^+-480) is flagged on the device and run by the general kernels in the same call.
  * Results: the same function as the general kernels (<= 1e-9 from the float64 oracle on log Z).
+ * (A launch captured into a HIP graph replays with the tag it was captured with: a lattice flagged in one replay stays
+ * with the general kernels in the following ones -- same results, their speed.)
  */
 #define NFST_CHK_META_WORDS 8
 #define NFST_CHK_C 0          /* chunks */
