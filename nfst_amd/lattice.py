@@ -485,7 +485,10 @@ class LatticeBatch:
         # deep, narrow lattices: the chunked programs are cut on the way to the device (once per host batch; a quick no
         # for every other shape) and travel with the batch
         if device.type == "cuda" and self.device.type == "cpu" and not self.__dict__.get("_chunks_tried", False) and auto_chunks:
-            self.build_chunks()
+            try:
+                self.build_chunks()
+            except _lib.NfstError:  # (a batch the cutter refuses runs the general kernels)
+                self.chunks, self._chunks_tried = None, True
         ck = self.__dict__.get("chunks")
         out.chunks = None if ck is None else ck.to(device, non_blocking=non_blocking)
         out._chunks_tried = self.__dict__.get("_chunks_tried", False)

@@ -185,3 +185,22 @@ def test_chunked_programs_for_a_batch_packed_on_the_device(dev):
     assert not lat.chunks.flagged().any()
     assert torch.max(torch.abs(r.logz64 - g.logz64)).item() <= 1e-7 and torch.max(torch.abs(r.posterior - g.posterior)).item() <= 2e-6
     _check(lat, lats, r, synth.label_scores(2, 64, mean=-1.0, std=0.5))
+
+
+def test_more_lattices_than_cus_use_the_smaller_workgroups(dev):
+    """2 B > 256 workgroups: the programs are cut for 512 threads and 64 KiB of LDS (two workgroups per CU)"""
+    rng = np.random.default_rng(77)
+    V = 48
+    lats = [synth.layered_lattice(7000 + i, n_states=int(rng.integers(30, 160)), avg_degree=3.0, vocab=V, width=int(rng.choice([1, 2, 3])),
+                                  span=int(rng.choice([1, 2])), max_degree=8) for i in range(160)]
+    host = LatticeBatch.from_synth(lats)
+    assert host.build_chunks(force=True)
+    assert host.chunks._h["threads"] == 512 and host.chunks._h["lds_bytes"] <= 64 * 1024
+    lat = host.to(dev)
+    theta = synth.label_scores(5, V, mean=-0.8, std=0.6)
+    r = ops.forward_backward(lat, torch.from_numpy(theta), want_grad_theta=True)
+    assert not lat.chunks.flagged().any()
+    _check(lat, lats, r, theta)
+    with _lib.tuning(chunked=0):
+        g = ops.forward_backward(lat, torch.from_numpy(theta), want_grad_theta=True)
+    assert torch.max(torch.abs(r.grad_theta - g.grad_theta)).item() <= 1e-4
