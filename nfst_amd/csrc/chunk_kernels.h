@@ -27,6 +27,7 @@ __host__ __device__ inline ChkWs chk_ws(const nfst_chunks &c) {
 }
 
 constexpr int kChkAhead = 8;   // entries a lane of pass 1 keeps in flight (NFST_CHK_SLACK in chunk_pack.cpp: twice that)
+constexpr int kChkNotYet = 0x7fffffff;  // vemax[c] before pass 2 has published chunk c's frontier values
 constexpr int kChkRange = 480;  // |binary exponent| of every weight and partial sum of pass 1: products stay normal
 
 // log weight of canonical arc `a` (absolute) of lattice b, in float64 (the oracle's sum)
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
   }
   for (int i = tid; i < C * ring_stride + 8 + C * F; i += NT) ring[i] = 0.0;  // (rings, the gap, vs)
   for (int i = tid; i <= C; i += NT) a_tab[i] = i < C ? tab[i * 4] : npos;
+  for (int i = tid; i < C; i += NT) vemax[i] = kChkNotYet;  // (pass 3 follows pass 2 chunk by chunk: "not published yet")
   // pass 2, step c (frontier of chunk c -> frontier of chunk c + 1): lane i computes the value at position p = a_{c+1} - 1 - i.
   // roff >= 0: the byte offset of p's row of T in the rings (p inside chunk c); -1: no such position (value zero);
   // -2 - f: p lies below chunk c (a chunk shorter than the frontier): the value of this step's frontier lane f passes through
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = row[j];  // (entries beyond F meet the zero of an idle lane)
     };
+    __builtin_amdgcn_s_setprio(3);              // (the waves that follow with pass 3 share its SIMD)
     int off = roff[fl];                         // step 0
     int off1 = roff[min(1, C - 1) * F + fl];    // step 1
     double r[8];
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
       bad |= (e != kEZero) & ((unsigned)(de + 250) > 500u);
       const double s = (e == kEZero) ? 0.0 : ldexp(m, max(min(de, 1000), -1000));  // (lanes from F up: zero)
       if (lane < F) vs[c * F + lane] = s;
+      asm volatile("" ::: "memory");  // (the exponent publishes the chunk: behind the values, and LDS executes a wave's accesses in order)
       if (lane == 0) vemax[c] = eref;
       if (c + 1 == C) break;
       // the next steps' operands (off the chain)
@@ -254,14 +258,19 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = rn[j];
     }
+    __builtin_amdgcn_s_setprio(0);
   }
-  __syncthreads();
   if (tid == 0) NFST_STAMP(3);
   // ---- pass 3: every position's value from its row of T and its chunk's frontier values, one position per thread and
   // trip (its chunk by bisection in LDS).  The range test of pass 1's sums happens here, off its chain.  (Tried: rows read
   // eight entries at a time into two accumulators, and the positions of a chunk dealt to its pass-1 lanes -- 4 .. 7 us
   // slower per launch on the batch of 64 than this plain loop.)
-  for (int p = tid; p < npos; p += NT) {
+  // The waves beside wave 0 do not wait for pass 2 to end: a position is computed as soon as its chunk's frontier values
+  // are published (its exponent in vemax); positions go up with the trips, so does the chunk a thread waits for.  A workgroup of one wave
+  // does the passes one after the other.
+  const bool follow = NT > 64;
+  for (int p = follow ? tid - 64 : tid; p < npos; p += follow ? NT - 64 : NT) {
+    if (p < 0) break;  // (wave 0 of a larger workgroup: pass 2 was its part)
     Rec64 v;
     if (p == 0) {
       v = Rec64{0.5, 1, 0};  // the start / the sink
@@ -270,6 +279,10 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (a_tab[mid] <= p) lo = mid; else hi = mid;
+      }
+      if (follow) {
+        while (((volatile int *)vemax)[lo] == kChkNotYet) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
       const double *row = T + (size_t)p * F;
       const double *sv = vs + lo * F;
