@@ -200,6 +200,7 @@ typedef struct nfst_chunks {
   const int32_t *tab;      /* [n_tab * 4]: first position, first entry (relative to the program), entries, 0 */
   const uint32_t *stream;  /* [n_stream] */
   const int32_t *pos;      /* [n_pos] position -> state */
+  const uint16_t *label;   /* [n_stream] the label of every entry's arc (saves the sweep kernel a dependent load) */
   void *ws;                /* device scratch of nfst_chunks_ws_bytes() bytes, owned by the caller and zeroed by it once (when
                               `launches` is zero), used by every launch on this batch (one launch at a time per batch) */
   int64_t ws_bytes;

@@ -57,7 +57,7 @@ class Chunks(C.Structure):  # nfst_chunks: the chunked programs of a batch of de
         ("n_lattices", C.c_int32), ("threads", C.c_int32), ("lds_bytes", C.c_int32), ("launches", C.c_int32),
         ("n_tab", C.c_int64), ("n_stream", C.c_int64), ("n_pos", C.c_int64), ("t_units", C.c_int64),
         ("total_rows", C.c_int64), ("total_arcs", C.c_int64),
-        ("meta", C.c_void_p), ("tab", C.c_void_p), ("stream", C.c_void_p), ("pos", C.c_void_p),
+        ("meta", C.c_void_p), ("tab", C.c_void_p), ("stream", C.c_void_p), ("pos", C.c_void_p), ("label", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 

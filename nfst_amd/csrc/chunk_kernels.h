@@ -77,9 +77,10 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
   unsigned bad = 0;
   if (tid == 0) NFST_STAMP(0);  // (profiling build: profiles/tune/chunk_stamps.py)
   // ---- the weights of this program's entries, in walking order: eight entries per thread and trip, every load of a
-  // stage issued before the first use (entry -> label -> score are dependent loads from HBM / L2)
+  // stage issued before the first use (entry and label, then the scores: dependent loads from HBM / L2)
   {
     const uint32_t *__restrict__ stream = ck.stream + cm[NFST_CHK_STREAM_OFF];
+    const uint16_t *__restrict__ labels = ck.label + cm[NFST_CHK_STREAM_OFF];  // (beside the entries: entry -> arc -> label would be a third load in the chain)
     const bool has_w = lat.weighted && lat.arc_w, has_s = sc.arc_scores != nullptr;
     const float *__restrict__ th = sc.theta + (size_t)sc.theta_stride * b;
     constexpr int kW = 8;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
 #pragma unroll
       for (int j = 0; j < kW; ++j) e[j] = stream[min(k0 + j * NT, n_entries - 1)];
 #pragma unroll
-      for (int j = 0; j < kW; ++j) { arc[j] = arc_off + (int)(e[j] >> 8); lab[j] = lat.arc_label[arc[j]]; }
+      for (int j = 0; j < kW; ++j) { arc[j] = arc_off + (int)(e[j] >> 8); lab[j] = labels[min(k0 + j * NT, n_entries - 1)]; }
 #pragma unroll
       for (int j = 0; j < kW; ++j) {
         t[j] = th[lab[j]];

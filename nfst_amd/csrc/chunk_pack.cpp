@@ -17,6 +17,7 @@ struct nfst_chunks_host {
   nfst_chunks view{};
   std::vector<int32_t> meta, tab, pos;
   std::vector<uint32_t> stream;
+  std::vector<uint16_t> label;
 };
 
 namespace {
@@ -160,7 +161,7 @@ bool cut(int n_rows, const std::vector<int32_t> &level, const std::vector<uint8_
 extern "C" int nfst_pack_chunks(const nfst_batch *hb, const nfst_chunk_opts *opts, nfst_chunks_host **out) {
   if (!hb || !out) return NFST_ERR_ARG;
   *out = nullptr;
-  if (hb->n_lattices <= 0 || !hb->meta || !hb->arc_src || !hb->arc_dst) return NFST_ERR_ARG;
+  if (hb->n_lattices <= 0 || !hb->meta || !hb->arc_src || !hb->arc_dst || !hb->arc_label) return NFST_ERR_ARG;
   nfst_chunk_opts o{};
   if (opts) o = *opts;
   const int B = hb->n_lattices;
@@ -246,11 +247,25 @@ extern "C" int nfst_pack_chunks(const nfst_batch *hb, const nfst_chunk_opts *opt
   }
   if (!o.force && cycles_chunked > 0.75 * cycles_general) { delete h; return NFST_OK; }
   h->stream.resize(h->stream.size() + 64, 0);  // (slack: a lane of pass 1 reads up to 24 entries ahead)
+  // the label of every entry's arc, beside the entry
+  h->label.assign(h->stream.size(), 0);
+  for (int b = 0; b < B; ++b) {
+    const int32_t *m = hb->meta + (size_t)b * NFST_META_WORDS;
+    for (int dir = 0; dir < 2; ++dir) {
+      const int32_t *cm = h->meta.data() + ((size_t)b * 2 + dir) * NFST_CHK_META_WORDS;
+      const int32_t *tb = h->tab.data() + (size_t)cm[NFST_CHK_TAB_OFF] * 4;
+      const int64_t n_e = tb[(cm[NFST_CHK_C] - 1) * 4 + 1] + tb[(cm[NFST_CHK_C] - 1) * 4 + 2];
+      for (int64_t k = 0; k < n_e; ++k) {
+        const uint32_t e = h->stream[cm[NFST_CHK_STREAM_OFF] + k];
+        if (!(e & NFST_CHK_ZERO)) h->label[cm[NFST_CHK_STREAM_OFF] + k] = (uint16_t)hb->arc_label[m[NFST_META_ARC_OFF] + (e >> 8)];
+      }
+    }
+  }
   nfst_chunks &v = h->view;
   v.n_lattices = B; v.threads = threads; v.lds_bytes = (int32_t)((lds_used + 255) & ~(int64_t)255); v.launches = 0;
   v.n_tab = (int64_t)h->tab.size() / 4; v.n_stream = (int64_t)h->stream.size(); v.n_pos = (int64_t)h->pos.size();
   v.t_units = t_units; v.total_rows = hb->total_rows; v.total_arcs = hb->total_arcs;
-  v.meta = h->meta.data(); v.tab = h->tab.data(); v.stream = h->stream.data(); v.pos = h->pos.data();
+  v.meta = h->meta.data(); v.tab = h->tab.data(); v.stream = h->stream.data(); v.pos = h->pos.data(); v.label = h->label.data();
   v.ws = nullptr; v.ws_bytes = 0;
   *out = h;
   return NFST_OK;

@@ -148,7 +148,7 @@ int chunked_launch(const nfst_batch *lat, const nfst_scores *scores, int n_dirs,
                    const int32_t **flags, int *tag) {
   nfst_chunks *ck = const_cast<nfst_chunks *>(lat->chunks);
   if (ck->n_lattices != lat->n_lattices || ck->total_rows != lat->total_rows || ck->total_arcs != lat->total_arcs || !ck->meta ||
-      !ck->tab || !ck->stream || !ck->pos || !ck->ws || ck->ws_bytes < nfst_chunks_ws_bytes(ck) || ck->threads < 64 ||
+      !ck->tab || !ck->stream || !ck->pos || !ck->label || !ck->ws || ck->ws_bytes < nfst_chunks_ws_bytes(ck) || ck->threads < 64 ||
       ck->threads > 1024 || (ck->threads & 63) || ck->lds_bytes <= 0 || ck->lds_bytes > kMaxLds || ((uintptr_t)ck->ws & 15))
     return NFST_ERR_ARG;
   ck->launches = ck->launches >= INT_MAX - 1 ? 1 : ck->launches + 1;

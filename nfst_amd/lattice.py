@@ -50,7 +50,7 @@ class ChunkProgram:
     direction the states in topological order, cut into chunks that are swept at the same time.  Built on the host by
     ``LatticeBatch.build_chunks`` (or by ``LatticeBatch.to`` when the cost model says the batch is one for this flavour);
     the device copy owns the scratch every launch on the batch uses (one launch at a time per batch)."""
-    _FIELDS = ("meta", "tab", "stream", "pos")
+    _FIELDS = ("meta", "tab", "stream", "pos", "label")
     _HEADER = ("n_lattices", "threads", "lds_bytes", "n_tab", "n_stream", "n_pos", "t_units", "total_rows", "total_arcs")
 
     def __init__(self, header: dict, tensors: dict):
@@ -75,7 +75,8 @@ class ChunkProgram:
             arrs = {"meta": _view(v.meta, v.n_lattices * 2 * _lib.CHK_META_WORDS, C.c_int32, np.int32),
                     "tab": _view(v.tab, v.n_tab * 4, C.c_int32, np.int32),
                     "stream": _view(v.stream, v.n_stream, C.c_int32, np.int32),
-                    "pos": _view(v.pos, v.n_pos, C.c_int32, np.int32)}
+                    "pos": _view(v.pos, v.n_pos, C.c_int32, np.int32),
+                    "label": _view(v.label, v.n_stream, C.c_int16, np.int16)}
             header = {k: int(getattr(v, k)) for k in cls._HEADER}
         finally:
             lib.nfst_chunks_free(handle)

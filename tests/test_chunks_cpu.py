@@ -76,6 +76,8 @@ def check_structure(lat: LatticeBatch, ck: ChunkProgram):
             e = stream[s_off:s_off + n_e]
             arcs = (e >> 8)[(e & ZERO) == 0]
             assert np.array_equal(np.sort(arcs), dp), "every arc of the lattice exactly once"
+            lab = ck._t["label"].numpy().view(np.uint16)[s_off:s_off + n_e]
+            assert np.array_equal(lab[(e & ZERO) == 0], lat.arc_label.numpy()[a0 + arcs]), "the label beside every entry"
             assert int(((e & LAST) != 0).sum()) == npos - 1
             pos = ck._t["pos"].numpy()[p_off:p_off + npos]
             assert len(set(pos.tolist())) == npos and pos[0] == (0 if d == 0 else int(lat.sink[b]))
