@@ -8,7 +8,14 @@ from nfst_amd import ops, synth, _lib
 from nfst_amd.lattice import LatticeBatch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda")
-host = LatticeBatch.from_synth(synth.snips_shaped_batch(B, vocab=250))
+if len(sys.argv) > 2 and sys.argv[2] == "narrow":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(8000)
+    lats = [synth.layered_lattice(8000 + i, n_states=int(rng.integers(400, 1501)), avg_degree=float(rng.choice([3.0, 5.0])), vocab=250,
+                                  width=int(rng.choice([1, 2, 3])), span=int(rng.choice([1, 2])), max_degree=40) for i in range(B)]
+else:
+    lats = synth.snips_shaped_batch(B, vocab=250)
+host = LatticeBatch.from_synth(lats)
 assert host.build_chunks(force=True)
 lat = host.to(dev)
 theta = torch.from_numpy(synth.label_scores(1, 250, mean=-1.5, std=0.8)).to(dev)

@@ -22,7 +22,14 @@ def timed(fn, n=50):
     return a.elapsed_time(b) / n * 1e3
 
 
-cases = [("snips_b64", synth.snips_shaped_batch(64, vocab=250), 250), ("snips_b1", synth.snips_shaped_batch(1, vocab=250), 250),
+def narrow_batch(n, seed=8000):
+    """tagging machines with one to three states per position only (what the chunked flavour is best at)"""
+    rng = np.random.default_rng(seed)
+    return [synth.layered_lattice(seed + i, n_states=int(rng.integers(400, 1501)), avg_degree=float(rng.choice([3.0, 5.0])), vocab=250,
+                                  width=int(rng.choice([1, 2, 3])), span=int(rng.choice([1, 2])), max_degree=40) for i in range(n)]
+
+
+cases = [("snips_b64", synth.snips_shaped_batch(64, vocab=250), 250), ("narrow_b64", narrow_batch(64), 250), ("narrow_b128", narrow_batch(128), 250), ("snips_b1", synth.snips_shaped_batch(1, vocab=250), 250),
          ("snips_b16", synth.snips_shaped_batch(16, vocab=250), 250),
          ("width4_b256", synth.bench_batch(256, width=4), 256), ("width4_b64", synth.bench_batch(64, width=4), 256),
          ("width2_b128", synth.bench_batch(128, width=2), 256)]
