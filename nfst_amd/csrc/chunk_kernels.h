@@ -9,7 +9,7 @@
 #pragma once
 
 struct ChkWs {
-  uint4 *rec;     // [n_stream] the entries with their weights: {weight (float64, two words), entry, 0}
+  uint4 *rec;     // [n_stream] the entries as pass 1 walks them: {weight (float64, two words), last-entry flag (sign bit), operand offset}
   double *T;      // [t_units * 64]
   Rec64 *me;      // [2][total_rows] alpha, beta of every row as (mantissa, exponent)
   Rec64 *zme;     // [n_lattices]
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
           bad |= (sco != sco) | ((x.e != kEZero) & ((unsigned)(x.e + kChkRange) > 2u * kChkRange));
           w = (x.e == kEZero) ? 0.0 : ldexp(x.m, max(min(x.e, 1000), -1000));
         }
-        // .w: the byte offset of the operand's slot in a lane's ring
-        rec[k] = make_uint4((uint32_t)__double2loint(w), (uint32_t)__double2hiint(w), e[j], (e[j] & 63u) * (uint32_t)(F * 8));
+        // .z: the sign bit says "last entry of its state" (one compare in the walk); .w: the byte offset of the operand's slot
+        rec[k] = make_uint4((uint32_t)__double2loint(w), (uint32_t)__double2hiint(w), (e[j] & NFST_CHK_LAST) ? 0x80000000u : 0u,
+                            (e[j] & 63u) * (uint32_t)(F * 8));
       }
     }
   }
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
     {                                                                             \
       const double w = __hiloint2double((int)(E).y, (int)(E).x);                  \
       acc = fma(*(const double *)(rb + (E).w), w, acc);                           \
-      if ((E).z & NFST_CHK_LAST) {                                                \
+      if ((int)(E).z < 0) {                                                       \
         *(double *)(rb + woff) = acc;                                             \
         *Tp = acc;                                                                \
         Tp += F;                                                                  \
