@@ -212,6 +212,8 @@ typedef struct nfst_chunk_opts {
   int32_t force;           /* 1 = cut every batch that can be cut (testing); 0 = only when the cost model of the
                               two flavours says the chunked one is faster */
   int32_t max_chunks;      /* 0 = no limit beside threads / LDS (testing: small values) */
+  int32_t n_threads;       /* host threads over lattices (0 = hardware) */
+  int32_t reserved;
 } nfst_chunk_opts;
 
 typedef struct nfst_chunks_host nfst_chunks_host; /* opaque, owns host arrays */

@@ -63,7 +63,8 @@ class Chunks(C.Structure):  # nfst_chunks: the chunked programs of a batch of de
 
 
 class ChunkOpts(C.Structure):
-    _fields_ = [("threads", C.c_int32), ("lds_bytes", C.c_int32), ("force", C.c_int32), ("max_chunks", C.c_int32)]
+    _fields_ = [("threads", C.c_int32), ("lds_bytes", C.c_int32), ("force", C.c_int32), ("max_chunks", C.c_int32),
+                ("n_threads", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Scores(C.Structure):

@@ -7,10 +7,12 @@
 #include "../../include/nfst_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 struct nfst_chunks_host {
@@ -39,6 +41,18 @@ struct Prog {
 };
 
 inline int pow2_at_least(int x) { int r = 1; while (r < x) r <<= 1; return r; }
+
+template <class Fn>
+void parallel_for(int n, int n_threads, Fn f) {
+  if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+  n_threads = std::max(1, std::min(n_threads, n));
+  if (n_threads == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) f(i); });
+  for (auto &x : th) x.join();
+}
 
 // LDS of a workgroup that runs a program with C chunks of F right-hand sides and R ring slots: the rings (one padded
 // block per chunk), the frontier values of every chunk (mantissa + exponent) and the chunks' first positions
@@ -181,16 +195,20 @@ extern "C" int nfst_pack_chunks(const nfst_batch *hb, const nfst_chunk_opts *opt
   int64_t t_units = 0;
   double cycles_chunked = 0.0, cycles_general = 0.0;
   int64_t lds_used = 0;
-  for (int b = 0; b < B; ++b) {
+  // per lattice, on host threads: both programs (or "cannot be cut"), then the programs are laid out one behind the other
+  struct One { int err = NFST_OK; bool ok = false; Prog p[2]; };
+  std::vector<One> ones(B);
+  parallel_for(B, o.n_threads, [&](int b) {
+    One &one = ones[b];
     const int32_t *m = hb->meta + (size_t)b * NFST_META_WORDS;
     const int n = m[NFST_META_N_ROWS], A = m[NFST_META_N_ARCS];
     const int32_t *src = hb->arc_src + m[NFST_META_ARC_OFF], *dst = hb->arc_dst + m[NFST_META_ARC_OFF];
-    if (A >= (1 << 24)) { delete h; return NFST_OK; }
+    if (A >= (1 << 24)) return;
     std::vector<uint8_t> reach(n, 0);
     reach[0] = 1;
     std::vector<int32_t> in_ptr(n + 1, 0), out_ptr(n + 1, 0);
     for (int a = 0; a < A; ++a) {
-      if (src[a] < 0 || src[a] >= n || dst[a] < 0 || dst[a] >= n) { delete h; return NFST_ERR_INDEX; }
+      if (src[a] < 0 || src[a] >= n || dst[a] < 0 || dst[a] >= n) { one.err = NFST_ERR_INDEX; return; }
       reach[src[a]] = 1; reach[dst[a]] = 1;
       if (src[a] != dst[a]) { in_ptr[dst[a] + 1]++; out_ptr[src[a] + 1]++; }
     }
@@ -215,18 +233,28 @@ extern "C" int nfst_pack_chunks(const nfst_batch *hb, const nfst_chunk_opts *opt
     }
     int n_reach = 0;
     for (int s = 0; s < n; ++s) n_reach += reach[s];
-    if ((int)order.size() != n_reach) { delete h; return NFST_ERR_CYCLE; }
+    if ((int)order.size() != n_reach) { one.err = NFST_ERR_CYCLE; return; }
     for (int i = n_reach - 1; i >= 0; --i) {
       const int s = order[i];
       for (int j = out_ptr[s]; j < out_ptr[s + 1]; ++j) height[s] = std::max(height[s], height[dst[out_list[j]]] + 1);
     }
     for (int dir = 0; dir < 2; ++dir) {
-      Prog p;
+      Prog &p = one.p[dir];
       const bool ok = dir == 0 ? cut(n, depth, reach, in_ptr, in_list, src, threads, lds_bytes, o.max_chunks, p)
                                : cut(n, height, reach, out_ptr, out_list, dst, threads, lds_bytes, o.max_chunks, p);
-      if (!ok) { delete h; return NFST_OK; }
       // position 0 must be the start (alpha) / the sink (beta)
-      if (p.pos[0] != (dir == 0 ? 0 : m[NFST_META_SINK])) { delete h; return NFST_OK; }
+      if (!ok || p.pos[0] != (dir == 0 ? 0 : m[NFST_META_SINK])) return;
+    }
+    one.ok = true;
+  });
+  for (int b = 0; b < B; ++b) {
+    if (ones[b].err != NFST_OK) { const int err = ones[b].err; delete h; return err; }
+    if (!ones[b].ok) { delete h; return NFST_OK; }
+  }
+  for (int b = 0; b < B; ++b) {
+    const int32_t *m = hb->meta + (size_t)b * NFST_META_WORDS;
+    for (int dir = 0; dir < 2; ++dir) {
+      const Prog &p = ones[b].p[dir];
       int32_t *cm = h->meta.data() + ((size_t)b * 2 + dir) * NFST_CHK_META_WORDS;
       cm[NFST_CHK_C] = p.C; cm[NFST_CHK_F] = p.F; cm[NFST_CHK_R] = p.R; cm[NFST_CHK_NPOS] = p.npos;
       cm[NFST_CHK_TAB_OFF] = (int32_t)(h->tab.size() / 4);

@@ -61,10 +61,10 @@ class ChunkProgram:
 
     @classmethod
     def build(cls, lat: "LatticeBatch", threads: int = 0, lds_bytes: int = 0, force: bool = False,
-              max_chunks: int = 0) -> "Optional[ChunkProgram]":
+              max_chunks: int = 0, n_threads: int = 0) -> "Optional[ChunkProgram]":
         if lat.device.type != "cpu":
             raise ValueError("chunked programs are cut from the host copy of a batch")
-        opts = _lib.ChunkOpts(int(threads), int(lds_bytes), 1 if force else 0, int(max_chunks))
+        opts = _lib.ChunkOpts(int(threads), int(lds_bytes), 1 if force else 0, int(max_chunks), int(n_threads), 0)
         handle = C.c_void_p()
         check(lib.nfst_pack_chunks(C.byref(lat.c_struct()), C.byref(opts), C.byref(handle)), "nfst_pack_chunks")
         if not handle:
