@@ -384,7 +384,7 @@ typedef struct nfst_scores {
  */
 int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbeta,
                   double *logz64, float *logz32, float *beta_me, void *stream);
-/* (lat->chunks != NULL and beta_me == NULL: the chunked flavour, see nfst_chunks) */
+/* (lat->chunks != NULL: the chunked flavour, see nfst_chunks) */
 
 /*
  * Full forward-backward: alpha and beta sweeps, log Z and arc posteriors

@@ -49,7 +49,7 @@ __device__ __forceinline__ double chk_readlane(double v, int lane) {
 __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_scores sc, nfst_chunks ck, int tag, int n_dirs,
                                                        float *__restrict__ logalpha, float *__restrict__ logbeta,
                                                        double *__restrict__ logz64, float *__restrict__ logz32,
-                                                       float *__restrict__ grad_theta) {
+                                                       float *__restrict__ grad_theta, float2 *__restrict__ beta_me) {
   extern __shared__ double chk_lds[];
   const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
   const int b = n_dirs == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
@@ -130,9 +130,11 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
   if (grad_theta && dir == 1)  // (k_chunk_post adds its workgroups' per-label sums into it)
     for (int l = tid; l < lat.vocab; l += NT) grad_theta[(size_t)b * lat.vocab + l] = 0.0f;
   // rows the program does not reach: -inf / zero (every reached row is overwritten below)
+  float2 *me32 = (beta_me && dir == 1) ? beta_me + row_off : nullptr;  // beta as float32 (mantissa, exponent) pairs: what nfst_sample_paths reads
   for (int i = tid; i < n_rows; i += NT) {
     if (logout) logout[row_off + i] = kNegInf;
     me[i] = Rec64{0.0, kEZero, 0};
+    if (me32) me32[i] = make_float2(0.0f, __int_as_float(kEZero));
   }
   // (what the lanes read below was written by this workgroup: a workgroup barrier orders it -- an agent-scope fence here
   // wrote the XCD's L2 back, 60 .. 100 us with 128 workgroups doing it)
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
     }
     const int state = pos[p];
     me[state] = v;
+    if (me32) me32[state] = me_f2(v);
     const double lg = me_log64(v);
     if (logout) logout[row_off + state] = (float)lg;
     if (dir == 1 && p == npos - 1) {

@@ -144,7 +144,7 @@ int precise_ring(const nfst_batch *lat, int64_t fixed, int n_rings) {
 // The chunked flavour (chunk_kernels.h): sweeps (one workgroup per lattice and direction), then posteriors / totals.  Returns
 // the device flags of the lattices that have to be run again by the general kernels (tagged *tag).
 int chunked_launch(const nfst_batch *lat, const nfst_scores *scores, int n_dirs, float *logalpha, float *logbeta, double *logz64,
-                   float *logz32, float *posterior, float *grad_theta, double *logz_total, int total_slot, hipStream_t st,
+                   float *logz32, float *posterior, float *grad_theta, float *beta_me, double *logz_total, int total_slot, hipStream_t st,
                    const int32_t **flags, int *tag) {
   nfst_chunks *ck = const_cast<nfst_chunks *>(lat->chunks);
   if (ck->n_lattices != lat->n_lattices || ck->total_rows != lat->total_rows || ck->total_arcs != lat->total_arcs || !ck->meta ||
@@ -157,7 +157,7 @@ int chunked_launch(const nfst_batch *lat, const nfst_scores *scores, int n_dirs,
   int rc;
   if ((rc = set_lds(k_chunk_sweep, ck->lds_bytes))) return rc;
   hipLaunchKernelGGL(k_chunk_sweep, dim3(lat->n_lattices * n_dirs), dim3(ck->threads), (size_t)ck->lds_bytes, st, *lat, *scores, *ck,
-                     *tag, n_dirs, logalpha, logbeta, logz64, logz32, grad_theta);
+                     *tag, n_dirs, logalpha, logbeta, logz64, logz32, grad_theta, (float2 *)beta_me);
   if (n_dirs == 2 && (posterior || grad_theta || logz_total)) {
     const size_t lds = grad_theta ? (size_t)lat->vocab * 4 : 0;
     // workgroups of 256 threads, about four arcs per thread of the largest lattice: a slice of a lattice's arcs each
@@ -324,15 +324,15 @@ int nfst_backward(const nfst_batch *lat, const nfst_scores *scores, float *logbe
   int rc = check_batch(lat);
   if (rc) return rc;
   if ((rc = check_scores(lat, scores))) return rc;
-  if (lat->chunks && tuning().chunked && !beta_me) {
+  if (lat->chunks && tuning().chunked) {
     // deep, narrow lattices: the chunked sweeps; lattices whose numbers leave their range are flagged on the device and
     // run by the general kernels below (a launch that finds no flag set returns at once)
     nfst_batch rest = *lat;
     rest.chunks = nullptr;
-    if ((rc = chunked_launch(lat, scores, 1, nullptr, logbeta, logz64, logz32, nullptr, nullptr, nullptr, 0, (hipStream_t)stream,
+    if ((rc = chunked_launch(lat, scores, 1, nullptr, logbeta, logz64, logz32, nullptr, nullptr, beta_me, nullptr, 0, (hipStream_t)stream,
                              &rest.only, &rest.only_tag)))
       return rc;
-    return nfst_backward(&rest, scores, logbeta, logz64, logz32, nullptr, stream);
+    return nfst_backward(&rest, scores, logbeta, logz64, logz32, beta_me, stream);
   }
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;
   const LdsPlan plan(lat->max_rows, lat->vocab);
@@ -392,13 +392,13 @@ int nfst_forward_backward(const nfst_batch *lat, const nfst_scores *scores, floa
   if (posterior && ((uintptr_t)posterior & 15)) return NFST_ERR_ARG;
   if (logz_total && (total_slot < 0 || total_slot > 2)) return NFST_ERR_ARG;
   if (!lat->arc_sd || !lat->arc_l16 || ((uintptr_t)lat->arc_sd & 15) || ((uintptr_t)lat->arc_l16 & 7)) return NFST_ERR_ARG;
-  if (lat->chunks && tuning().chunked && !beta_me) {  // (as in nfst_backward)
+  if (lat->chunks && tuning().chunked) {  // (as in nfst_backward)
     nfst_batch rest = *lat;
     rest.chunks = nullptr;
-    if ((rc = chunked_launch(lat, scores, 2, logalpha, logbeta, logz64, logz32, posterior, grad_theta, logz_total, (int)total_slot,
+    if ((rc = chunked_launch(lat, scores, 2, logalpha, logbeta, logz64, logz32, posterior, grad_theta, beta_me, logz_total, (int)total_slot,
                              (hipStream_t)stream, &rest.only, &rest.only_tag)))
       return rc;
-    return nfst_forward_backward(&rest, scores, logalpha, logbeta, logz64, logz32, posterior, grad_theta, nullptr, logz_total, total_slot,
+    return nfst_forward_backward(&rest, scores, logalpha, logbeta, logz64, logz32, posterior, grad_theta, beta_me, logz_total, total_slot,
                                  stream);
   }
   const bool extra = (lat->weighted && lat->arc_w) || scores->arc_scores;

@@ -204,3 +204,35 @@ def test_more_lattices_than_cus_use_the_smaller_workgroups(dev):
     with _lib.tuning(chunked=0):
         g = ops.forward_backward(lat, torch.from_numpy(theta), want_grad_theta=True)
     assert torch.max(torch.abs(r.grad_theta - g.grad_theta)).item() <= 1e-4
+
+
+def test_beta_pairs_and_sampling_through_the_chunked_flavour(dev):
+    """beta_me (float32 mantissa / exponent pairs, what nfst_sample_paths walks on) from the chunked sweeps: the same numbers as
+    the general kernels', and posterior samples whose log q is path score - log Z"""
+    V = 64
+    lats = synth.snips_shaped_batch(6, vocab=V, first_seed=6100)
+    host = LatticeBatch.from_synth(lats)
+    assert host.build_chunks(force=True)
+    lat = host.to(dev)
+    theta = synth.label_scores(4, V, mean=-1.0, std=0.6)
+    th = torch.from_numpy(theta)
+    b = ops.backward(lat, th, want_me=True)
+    assert not lat.chunks.flagged().any()
+    with _lib.tuning(chunked=0):
+        g = ops.backward(lat, th, want_me=True)
+    mb, mg = b.beta_me.cpu().numpy(), g.beta_me.cpu().numpy()
+    eb, eg = mb[:, 1].view(np.int32), mg[:, 1].view(np.int32)
+    live = mg[:, 0] > 0
+    assert np.array_equal(mb[:, 0] > 0, live)
+    vb = np.log(mb[live, 0].astype(np.float64)) + eb[live] * np.log(2.0)
+    vg = np.log(mg[live, 0].astype(np.float64)) + eg[live] * np.log(2.0)
+    assert np.max(np.abs(vb - vg)) <= 2e-6
+    K = 64
+    s = ops.sample_paths(lat, th, K, seed=3, beta=b)
+    arcs, lens, logq = s.arcs.cpu().numpy(), s.lengths.cpu().numpy(), s.logq.cpu().numpy()
+    for i, l in enumerate(lats):
+        order = _canonical(l)
+        sc = theta[l.label].astype(np.float64)[order]
+        for k in range(0, K, 7):
+            a = arcs[i, k, :lens[i, k]] - int(lat.arc_off[i])
+            assert abs(sc[a].sum() - float(b.logz64[i]) - logq[i, k]) <= 5e-5 * max(1.0, abs(float(b.logz64[i])) / 100)
