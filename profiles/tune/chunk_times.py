@@ -29,7 +29,7 @@ def narrow_batch(n, seed=8000):
                                   width=int(rng.choice([1, 2, 3])), span=int(rng.choice([1, 2])), max_degree=40) for i in range(n)]
 
 
-cases = [("snips_b64", synth.snips_shaped_batch(64, vocab=250), 250), ("narrow_b64", narrow_batch(64), 250), ("narrow_b128", narrow_batch(128), 250), ("snips_b1", synth.snips_shaped_batch(1, vocab=250), 250),
+cases = [("snips_b64", synth.snips_shaped_batch(64, vocab=250), 250), ("narrow_b64", narrow_batch(64), 250), ("narrow_b128", narrow_batch(128), 250), ("narrow_b256", narrow_batch(256), 250), ("narrow_b512", narrow_batch(512), 250), ("snips_b1", synth.snips_shaped_batch(1, vocab=250), 250),
          ("snips_b16", synth.snips_shaped_batch(16, vocab=250), 250),
          ("width4_b256", synth.bench_batch(256, width=4), 256), ("width4_b64", synth.bench_batch(64, width=4), 256),
          ("width2_b128", synth.bench_batch(128, width=2), 256)]
