@@ -423,6 +423,12 @@ def aux_single_gpu(dev, theta256, steps):
     # batch size 1: the reference's decoder scores one lattice at a time (src/decode/decoder.py:77-79)
     one = LatticeBatch.from_synth(lats[:1], device=dev)
     aux["decode_b1_snips_shaped"] = dict(fb_line(one, th), viterbi_ms=time_op(lambda: ops.viterbi(one, th), iters))
+    # ... and one deep, narrow machine (two states per position, 750 levels): the chunked flavour on two CUs
+    deep1 = LatticeBatch.from_synth([synth.layered_lattice(4242, n_states=1500, avg_degree=3.0, vocab=lats[0].vocab, width=2, span=1, max_degree=40)], device=dev)
+    aux["decode_b1_deep_narrow"] = dict(fb_line(deep1, th), flavour="chunked" if deep1.chunks is not None else "general")
+    with _lib.tuning(chunked=0):
+        aux["decode_b1_deep_narrow"]["general_kernels_ms_per_step"] = fb_line(deep1, th)["ms_per_step"]
+    del deep1
     lats1 = synth.bench_batch(1, first_seed=1234)
     one = LatticeBatch.from_synth(lats1, device=dev)
     aux["decode_b1_configs1_lattice"] = dict(fb_line(one, theta256), viterbi_ms=time_op(lambda: ops.viterbi(one, theta256), iters))

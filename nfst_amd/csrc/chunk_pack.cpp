@@ -30,7 +30,7 @@ constexpr int kMaxReach = 63;    // an entry's operand slot has 6 bits
 // section 4.4): pass 1 is the longest chunk at one entry per kEntry cycles (an LDS round trip per entry on a lane's chain),
 // or -- when the workgroup's lanes keep the CU's issue slots busy -- the whole program's entries x F / 64 lanes x kIssue / 4
 // SIMDs; pass 2 is C steps of step_cycles(F); kFixed: weights, initialisation, pass 3, the second kernel
-constexpr double kEntry = 220.0, kIssue = 60.0, kFixed = 40000.0;
+constexpr double kEntry = 220.0, kIssue = 60.0, kFixed = 25000.0;
 inline double step_cycles(int F) { return 700.0 + 380.0 * ((F + 7) / 8 - 1); }
 
 struct Prog {
@@ -183,12 +183,9 @@ extern "C" int nfst_pack_chunks(const nfst_batch *hb, const nfst_chunk_opts *opt
   const int threads = o.threads > 0 ? o.threads : (roomy ? 1024 : 512);
   const int64_t lds_bytes = o.lds_bytes > 0 ? o.lds_bytes : (roomy ? 152 * 1024 : 64 * 1024);
   if (threads < 64 || threads > 1024 || (threads & 63) || lds_bytes > 160 * 1024) return NFST_ERR_ARG;
-  // a quick no: programs with well-filled tiles (the BASELINE shape) are not for this flavour
-  if (!o.force) {
-    int64_t tiles = 0;
-    for (int b = 0; b < B; ++b) tiles += hb->meta[(size_t)b * NFST_META_WORDS + NFST_META_BWD_TILES];
-    if (tiles * 64 < 2 * hb->total_arcs) return NFST_OK;
-  }
+  // a quick no: up to ~160 levels the general kernels are done before the fixed costs of this flavour are (the BASELINE shape:
+  // 130 .. 150 tiles)
+  if (!o.force && hb->max_tiles <= 160) return NFST_OK;
   nfst_chunks_host *h = new (std::nothrow) nfst_chunks_host();
   if (!h) return NFST_ERR_NOMEM;
   h->meta.assign((size_t)B * 2 * NFST_CHK_META_WORDS, 0);
@@ -273,7 +270,7 @@ extern "C" int nfst_pack_chunks(const nfst_batch *hb, const nfst_chunk_opts *opt
     const int tiles = std::max(m[NFST_META_FWD_TILES], m[NFST_META_BWD_TILES]);
     cycles_general = std::max(cycles_general, tiles * (tiles > 192 ? 500.0 : 400.0) * std::max(1.0, (double)B / kCus) + 12000.0);
   }
-  if (!o.force && cycles_chunked > 0.75 * cycles_general) { delete h; return NFST_OK; }
+  if (!o.force && cycles_chunked > 0.9 * cycles_general) { delete h; return NFST_OK; }  // (profiles/tune/chunk_auto.py: the choice against measurements)
   h->stream.resize(h->stream.size() + 64, 0);  // (slack: a lane of pass 1 reads up to 24 entries ahead)
   // the label of every entry's arc, beside the entry
   h->label.assign(h->stream.size(), 0);
