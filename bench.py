@@ -416,6 +416,8 @@ def aux_single_gpu(dev, theta256, steps):
     # (deep and narrow: the packer cut chunked programs on the way to the device; the general kernels on the same batch beside it)
     from nfst_amd import _lib
     aux["configs2_snips_shaped_b64"]["flavour"] = "chunked" if lat.chunks is not None else "general"
+    if lat.chunks is not None:  # (lattices the chunked kernels handed back to the general ones: none expected on these scores)
+        aux["configs2_snips_shaped_b64"]["handed_back_to_general_kernels"] = int(lat.chunks.flagged().sum())
     aux["configs2_snips_shaped_b64"]["beta_only_ms"] = time_op(lambda: ops.backward(lat, th, want_logbeta=False), iters)
     with _lib.tuning(chunked=0):
         aux["configs2_snips_shaped_b64"]["general_kernels_ms_per_step"] = fb_line(lat, th)["ms_per_step"]
