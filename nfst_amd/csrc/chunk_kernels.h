@@ -44,6 +44,77 @@ __device__ __forceinline__ double chk_readlane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Pass 2 of k_chunk_sweep on one wave: the frontier values chained through the chunks.  Lane i holds the value at position
+// a_c - 1 - i as (m, e); a step scales them to lane 0's exponent, multiplies with the F x F block of T the chunk's ring
+// still holds, and normalises.  One wave, in order: what a step costs is its instruction count (~320 ns at F = 8, a third
+// less at F <= 2: NB = the row entries a lane keeps, 2, 4 or 8; frontiers beyond 8 states take a tail loop).  The chain is
+// ALU only -- the frontier values reach the other lanes by v_readlane (the scaled value of lane f is a scalar operand of
+// lane i's multiply-add) -- and the first NB entries of a lane's row of T for the NEXT step are read from the ring while
+// this step computes, from an offset looked up one step before that (roff, filled by all threads before pass 1).
+// Returns non-zero when the frontier values of a step lie further apart than 2^250 (the lattice goes to the general kernels).
+template <int NB>
+__device__ __forceinline__ unsigned chk_chain(const double *ring, double *vs, int *vemax, const int *roff, int C, int F, int lane) {
+  unsigned bad = 0;
+  double m = (lane == 0) ? 1.0 : 0.0;  // chunk 0: position 0 (the start / the sink) has value one
+  int e = (lane == 0) ? 0 : kEZero;
+  const char *lds0 = (const char *)ring;
+  const int fl = min(lane, F - 1);
+  auto load = [&](int off, double (&r)[NB]) {
+    const double *row = (const double *)(lds0 + max(off, 0));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) r[j] = row[j];  // (entries beyond F meet the zero of an idle lane)
+  };
+  int off = roff[fl];                         // step 0
+  int off1 = roff[min(1, C - 1) * F + fl];    // step 1
+  double r[NB];
+  load(off, r);
+  for (int c = 0; c < C; ++c) {
+    // a common exponent for the step: lane 0's (the frontier state next to the chunk); the others must lie within
+    // 2^+-250 of it
+    int eref = __builtin_amdgcn_readfirstlane(e);
+    if (eref == kEZero)
+      for (int f = 1; f < F; ++f) eref = max(eref, __builtin_amdgcn_readlane(e, f));
+    const int de = e - eref;
+    bad |= (e != kEZero) & ((unsigned)(de + 250) > 500u);
+    const double s = (e == kEZero) ? 0.0 : ldexp(m, max(min(de, 1000), -1000));  // (lanes from F up: zero)
+    if (lane < F) vs[c * F + lane] = s;
+    asm volatile("" ::: "memory");  // (the exponent publishes the chunk: behind the values, and LDS executes a wave's accesses in order)
+    if (lane == 0) vemax[c] = eref;
+    if (c + 1 == C) break;
+    // the next steps' operands (off the chain)
+    const int off2 = roff[min(c + 2, C - 1) * F + fl];
+    double rn[NB];
+    load(off1, rn);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j & 3] = fma(r[j], chk_readlane(s, j), acc[j & 3]);
+    if (NB == 8) {
+      for (int f0 = 8; f0 < F; f0 += 8) {  // (frontiers beyond eight states: these reads are on the chain)
+        load(off + f0 * 8, r);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j & 3] = fma(r[j], chk_readlane(s, f0 + j), acc[j & 3]);
+      }
+    }
+    const double sum = NB == 2 ? acc[0] + acc[1] : (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    const bool inside = lane < F && off >= 0;
+    double m_new = inside ? __builtin_amdgcn_frexp_mant(sum) : 0.0;
+    int e_new = (inside && sum != 0.0) ? eref + __builtin_amdgcn_frexp_exp(sum) : kEZero;
+    if (__any(lane < F && off <= -2)) {  // a chunk shorter than the frontier: positions below it pass through
+      const bool below = lane < F && off <= -2;
+      const int src_lane = below ? -2 - off : lane;
+      const double m_pass = __shfl(m, src_lane);
+      const int e_pass = __shfl(e, src_lane);
+      if (below) { m_new = m_pass; e_new = e_pass; }
+    }
+    m = m_new;
+    e = e_new;
+    off = off1; off1 = off2;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) r[j] = rn[j];
+  }
+  return bad;
+}
+
 // One workgroup per (lattice, direction).  n_dirs = 2: blockIdx = 2 * lattice + direction (0 alpha, 1 beta);
 // n_dirs = 1: the beta programs only (nfst_backward).
 __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_scores sc, nfst_chunks ck, int tag, int n_dirs,
@@ -192,76 +263,12 @@ __global__ __launch_bounds__(1024) void k_chunk_sweep(nfst_batch lat, nfst_score
   }
   __syncthreads();
   if (tid == 0) NFST_STAMP(2);
-  // ---- pass 2 (wave 0): the frontier values chained through the chunks.  Lane i holds the value at position
-  // a_c - 1 - i as (m, e); a step scales them to the largest exponent (uniform), multiplies with the F x F block of T the
-  // chunk's ring still holds, and normalises.
+  // ---- pass 2 (wave 0): the frontier values chained through the chunks (chk_chain above)
   if (tid < 64) {
-    double m = (tid == 0) ? 1.0 : 0.0;  // chunk 0: position 0 (the start / the sink) has value one
-    int e = (tid == 0) ? 0 : kEZero;
-    // One wave, in order: what a step costs is its instruction count.  The chain is ALU only -- the frontier values reach
-    // the other lanes by v_readlane (the scaled value of lane f is a scalar operand of lane i's multiply-add) -- and the
-    // first eight entries of a lane's row of T for the NEXT step are read from the ring while this step computes, from an
-    // offset looked up one step before that (roff, filled by all threads above).
-    const char *lds0 = (const char *)ring;
-    const int fl = min(lane, F - 1);
-    auto load8 = [&](int off, double (&r)[8]) {
-      const double *row = (const double *)(lds0 + max(off, 0));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = row[j];  // (entries beyond F meet the zero of an idle lane)
-    };
-    __builtin_amdgcn_s_setprio(3);              // (the waves that follow with pass 3 share its SIMD)
-    int off = roff[fl];                         // step 0
-    int off1 = roff[min(1, C - 1) * F + fl];    // step 1
-    double r[8];
-    load8(off, r);
-    for (int c = 0; c < C; ++c) {
-      // a common exponent for the step: lane 0's (the frontier state next to the chunk); the others must lie within
-      // 2^+-250 of it or the lattice goes to the general kernels
-      int eref = __builtin_amdgcn_readfirstlane(e);
-      if (eref == kEZero)
-        for (int f = 1; f < F; ++f) eref = max(eref, __builtin_amdgcn_readlane(e, f));
-      const int de = e - eref;
-      bad |= (e != kEZero) & ((unsigned)(de + 250) > 500u);
-      const double s = (e == kEZero) ? 0.0 : ldexp(m, max(min(de, 1000), -1000));  // (lanes from F up: zero)
-      if (lane < F) vs[c * F + lane] = s;
-      asm volatile("" ::: "memory");  // (the exponent publishes the chunk: behind the values, and LDS executes a wave's accesses in order)
-      if (lane == 0) vemax[c] = eref;
-      if (c + 1 == C) break;
-      // the next steps' operands (off the chain)
-      const int off2 = roff[min(c + 2, C - 1) * F + fl];
-      double rn[8];
-      load8(off1, rn);
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-#define NFST_CHK_MAC(ACC, J) ACC = fma(r[J], chk_readlane(s, f0 + (J)), ACC)
-      {
-        const int f0 = 0;
-        NFST_CHK_MAC(acc0, 0); NFST_CHK_MAC(acc1, 1);
-        if (F > 2) { NFST_CHK_MAC(acc2, 2); NFST_CHK_MAC(acc3, 3); }
-        if (F > 4) { NFST_CHK_MAC(acc0, 4); NFST_CHK_MAC(acc1, 5); NFST_CHK_MAC(acc2, 6); NFST_CHK_MAC(acc3, 7); }
-      }
-      for (int f0 = 8; f0 < F; f0 += 8) {  // (frontiers beyond eight states: these reads are on the chain)
-        load8(off + f0 * 8, r);
-        NFST_CHK_MAC(acc0, 0); NFST_CHK_MAC(acc1, 1); NFST_CHK_MAC(acc2, 2); NFST_CHK_MAC(acc3, 3);
-        NFST_CHK_MAC(acc0, 4); NFST_CHK_MAC(acc1, 5); NFST_CHK_MAC(acc2, 6); NFST_CHK_MAC(acc3, 7);
-      }
-#undef NFST_CHK_MAC
-      const double acc = (acc0 + acc1) + (acc2 + acc3);
-      const bool inside = lane < F && off >= 0;
-      double m_new = inside ? __builtin_amdgcn_frexp_mant(acc) : 0.0;
-      int e_new = (inside && acc != 0.0) ? eref + __builtin_amdgcn_frexp_exp(acc) : kEZero;
-      if (__any(lane < F && off <= -2)) {  // a chunk shorter than the frontier: positions below it pass through
-        const bool below = lane < F && off <= -2;
-        const int src_lane = below ? -2 - off : lane;
-        const double m_pass = __shfl(m, src_lane);
-        const int e_pass = __shfl(e, src_lane);
-        if (below) { m_new = m_pass; e_new = e_pass; }
-      }
-      m = m_new;
-      e = e_new;
-      off = off1; off1 = off2;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = rn[j];
-    }
+    __builtin_amdgcn_s_setprio(3);  // (the waves that follow with pass 3 share its SIMD)
+    if (F <= 2) bad |= chk_chain<2>(ring, vs, vemax, roff, C, F, lane);
+    else if (F <= 4) bad |= chk_chain<4>(ring, vs, vemax, roff, C, F, lane);
+    else bad |= chk_chain<8>(ring, vs, vemax, roff, C, F, lane);
     __builtin_amdgcn_s_setprio(0);
   }
   if (tid == 0) NFST_STAMP(3);

@@ -31,7 +31,7 @@ constexpr int kMaxReach = 63;    // an entry's operand slot has 6 bits
 // or -- when the workgroup's lanes keep the CU's issue slots busy -- the whole program's entries x F / 64 lanes x kIssue / 4
 // SIMDs; pass 2 is C steps of step_cycles(F); kFixed: weights, initialisation, pass 3, the second kernel
 constexpr double kEntry = 220.0, kIssue = 60.0, kFixed = 25000.0;
-inline double step_cycles(int F) { return 700.0 + 380.0 * ((F + 7) / 8 - 1); }
+inline double step_cycles(int F) { return (F <= 2 ? 560.0 : F <= 4 ? 600.0 : 775.0) + 300.0 * ((F + 7) / 8 - 1); }  // (234 / 250 / 322 / 445 ns at F = 2 / 3 / 8 / 16)
 
 struct Prog {
   int C = 0, F = 0, R = 0, npos = 0;
