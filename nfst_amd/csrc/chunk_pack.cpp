@@ -27,9 +27,10 @@ namespace {
 constexpr int kCus = 256;        // MI355X
 constexpr int kMaxReach = 63;    // an entry's operand slot has 6 bits
 // cost model of the chunked sweep (cycles at 2.4 GHz, MI355X, measured with profiles/tune/chunk_stamps.py: DESIGN.md
-// section 4.4): pass 1 is the longest chunk at one entry per kEntry cycles (an LDS round trip per entry on a lane's chain),
-// or -- when the workgroup's lanes keep the CU's issue slots busy -- the whole program's entries x F / 64 lanes x kIssue / 4
-// SIMDs; pass 2 is C steps of step_cycles(F); kFixed: weights, initialisation, pass 3, the second kernel
+// section 4.4): pass 1 is the longest chunk at one entry per kEntry cycles (an LDS round trip per entry on a lane's chain:
+// 82 ns with one wave per SIMD, 88 ns with three), or -- a bound for workgroups full of lanes -- the whole program's entries
+// x F / 64 lanes x kIssue / 4 SIMDs; pass 2 is C steps of step_cycles(F); kFixed: weights, initialisation, the tail of pass 3,
+// the second kernel and the empty launch of the general one
 constexpr double kEntry = 220.0, kIssue = 60.0, kFixed = 25000.0;
 inline double step_cycles(int F) { return (F <= 2 ? 560.0 : F <= 4 ? 600.0 : 775.0) + 300.0 * ((F + 7) / 8 - 1); }  // (234 / 250 / 322 / 445 ns at F = 2 / 3 / 8 / 16)
 
@@ -145,7 +146,6 @@ bool cut(int n_rows, const std::vector<int32_t> &level, const std::vector<uint8_
   out.C = C; out.F = F; out.R = R; out.npos = n;
   out.pos.assign(order.begin(), order.end());
   out.tab.clear(); out.stream.clear();
-  int64_t longest = 0;
   for (int c = 0; c < C; ++c) {
     const int a = starts[c], b = c + 1 < C ? starts[c + 1] : n;
     const int64_t begin = (int64_t)out.stream.size();
@@ -162,10 +162,8 @@ bool cut(int n_rows, const std::vector<int32_t> &level, const std::vector<uint8_
     // (a chunk's entries are walked eight at a time without a bounds test: padded with zero-weight entries)
     while ((out.stream.size() - begin) % 8) out.stream.push_back(NFST_CHK_ZERO);
     const int64_t count = (int64_t)out.stream.size() - begin;
-    longest = std::max(longest, count);
     out.tab.push_back(a); out.tab.push_back((int32_t)begin); out.tab.push_back((int32_t)count); out.tab.push_back(0);
   }
-  (void)longest;
   out.cycles = best.cycles;
   return true;
 }
