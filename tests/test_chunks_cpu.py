@@ -150,3 +150,33 @@ def test_which_batches_get_chunked_programs():
     assert not wide.build_chunks(force=True)  # levels of 48 states: an arc reaches more than 63 positions back
     with pytest.raises(_lib.NfstError):
         ChunkProgram.build(snips, threads=100)  # not a multiple of 64
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_cuts_replayed_on_the_host(seed):
+    """random narrow lattices, random workgroup sizes / LDS budgets / chunk limits: the structure of every program and the replayed
+    passes against the oracle (the host-side twin of test_gpu_chunks.test_fuzz_chunked_flavour_against_oracle)"""
+    rng = np.random.default_rng(4000 + seed)
+    V = int(rng.choice([24, 64]))
+    lats = []
+    while len(lats) < int(rng.integers(1, 6)):
+        try:
+            lats.append(synth.layered_lattice(int(rng.integers(1, 1 << 30)), n_states=int(rng.choice([4, 9, 30, 80, 200])),
+                                              avg_degree=float(rng.choice([1.5, 3.0, 5.0])), vocab=V, width=int(rng.choice([1, 2, 3, 5, 8])),
+                                              span=int(rng.choice([1, 2, 3])), max_degree=min(10, (V - 12) // 2)))
+        except AssertionError:
+            continue
+    lat = LatticeBatch.from_synth(lats)
+    opts = dict(threads=int(rng.choice([64, 128, 512, 1024])), max_chunks=int(rng.choice([0, 0, 1, 2, 5])), lds_bytes=int(rng.choice([0, 8192, 32768])))
+    if not lat.build_chunks(force=True, **opts):
+        pytest.skip("no cut within these limits")
+    check_structure(lat, lat.chunks)
+    theta = synth.label_scores(seed, V, mean=-0.2, std=0.6)
+    for b, l in enumerate(lats):
+        sc, o = oracle_values(l, theta)
+        w = np.exp(sc[np.lexsort((l.label, l.src))])
+        for d, key in ((0, "logalpha"), (1, "logbeta")):
+            with np.errstate(divide="ignore"):
+                got = np.log(replay(lat, lat.chunks, b, d, w))
+            fin = np.isfinite(o[key])
+            assert np.array_equal(np.isfinite(got), fin) and np.max(np.abs(got[fin] - o[key][fin])) <= 1e-9, (b, d)
