@@ -31,7 +31,7 @@ constexpr int kMaxReach = 63;    // an entry's operand slot has 6 bits
 // 82 ns with one wave per SIMD, 88 ns with three), or -- a bound for workgroups full of lanes -- the whole program's entries
 // x F / 64 lanes x kIssue / 4 SIMDs; pass 2 is C steps of step_cycles(F); kFixed: weights, initialisation, the tail of pass 3,
 // the second kernel and the empty launch of the general one
-constexpr double kEntry = 220.0, kIssue = 60.0, kFixed = 25000.0;
+constexpr double kEntry = 205.0, kIssue = 60.0, kFixed = 25000.0;
 inline double step_cycles(int F) { return (F <= 2 ? 560.0 : F <= 4 ? 600.0 : 775.0) + 300.0 * ((F + 7) / 8 - 1); }  // (234 / 250 / 322 / 445 ns at F = 2 / 3 / 8 / 16)
 
 struct Prog {
@@ -100,8 +100,8 @@ bool cut(int n_rows, const std::vector<int32_t> &level, const std::vector<uint8_
   // allow, about the same number of entries each; a cut whose frontier is wider than Ft moves to the nearest position
   // where it is not (or is dropped).  The cheapest plan over all Ft by the cost model wins.
   struct Plan { std::vector<int32_t> starts; int F = 0; double cycles = 0.0; };
-  auto plan_for = [&](int Ft, Plan &pl) {
-    int C = std::min(threads / Ft, n - 1);
+  auto plan_for = [&](int Ft, int lane_cap, Plan &pl) {
+    int C = std::min(std::min(threads, lane_cap) / Ft, n - 1);
     C = std::min(C, std::max(1, (int)std::ceil(std::sqrt((double)total * kEntry / step_cycles(Ft)))));
     while (C > 1 && lds_need(C, Ft, R) > lds_bytes) --C;
     if (max_chunks > 0) C = std::min(C, max_chunks);
@@ -128,16 +128,21 @@ bool cut(int n_rows, const std::vector<int32_t> &level, const std::vector<uint8_
       const int64_t cnt = pre[c + 1 < pl.starts.size() ? pl.starts[c + 1] : n] - pre[pl.starts[c]];
       longest = std::max(longest, (cnt + 7) / 8 * 8);
     }
-    pl.cycles = std::max((double)longest * kEntry, (double)total * pl.F / 64.0 * kIssue / 4.0) +
+    // an entry of pass 1 is an LDS round trip on its lane's chain while a SIMD holds at most two of the workgroup's waves
+    // (82 .. 88 ns); with a third one the walks share its issue slots (88 .. 113 ns with nine waves, 112 .. 139 with twelve)
+    const int waves = ((int)pl.starts.size() * pl.F + 63) / 64, per_simd = (waves + 3) / 4;
+    const double entry = kEntry + 60.0 * std::max(0, per_simd - 2);
+    pl.cycles = std::max((double)longest * entry, (double)total * pl.F / 64.0 * kIssue / 4.0) +
                 (double)pl.starts.size() * step_cycles(pl.F) + kFixed;
     return true;
   };
   Plan best;
-  for (int Ft = Fb; Ft >= 1; --Ft) {
-    Plan pl;
-    if (!plan_for(Ft, pl)) continue;
-    if (best.F == 0 || pl.cycles < best.cycles) best = pl;
-  }
+  for (int Ft = Fb; Ft >= 1; --Ft)
+    for (int lane_cap : {1024, 512}) {  // (fewer chunks can be faster: two waves per SIMD)
+      Plan pl;
+      if (!plan_for(Ft, lane_cap, pl)) continue;
+      if (best.F == 0 || pl.cycles < best.cycles) best = pl;
+    }
   if (best.F == 0) return false;
   const std::vector<int32_t> &starts = best.starts;
   const int F = best.F;
