@@ -156,7 +156,9 @@ class DevicePrefetcher:
             except StopIteration:
                 nxt = None
             torch.cuda.current_stream(self.device).wait_event(cur[1])
-            for t in cur[0]._t.values():
+            main = torch.cuda.current_stream(self.device)
+            ck = cur[0].chunks  # (a batch of deep, narrow lattices: its chunked programs and their scratch were allocated on the side stream too)
+            for t in list(cur[0]._t.values()) + ([] if ck is None else list(ck._t.values()) + [ck.ws]):
                 if t is not None:
-                    t.record_stream(torch.cuda.current_stream(self.device))
+                    t.record_stream(main)
             yield cur[0]

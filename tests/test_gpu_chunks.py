@@ -236,3 +236,22 @@ def test_beta_pairs_and_sampling_through_the_chunked_flavour(dev):
         for k in range(0, K, 7):
             a = arcs[i, k, :lens[i, k]] - int(lat.arc_off[i])
             assert abs(sc[a].sum() - float(b.logz64[i]) - logq[i, k]) <= 5e-5 * max(1.0, abs(float(b.logz64[i])) / 100)
+
+
+def test_chunked_programs_through_the_device_prefetcher(dev):
+    """io.DevicePrefetcher (pinned staging, copies on a side stream): batches of deep, narrow lattices arrive with their chunked
+    programs cut and their scratch in place; results are those of a plain blocking copy"""
+    from nfst_amd import io
+    V = 64
+    theta = torch.from_numpy(synth.label_scores(5, V, mean=-1.0, std=0.5))
+    cpu = [LatticeBatch.from_synth([synth.layered_lattice(900 + 10 * i + j, n_states=400 + 100 * j, avg_degree=3.0, vocab=V, width=2, span=1,
+                                                           max_degree=8) for j in range(3)]) for i in range(4)]
+    want = [ops.forward_backward(b.to(dev), theta) for b in cpu]
+    assert all(b.chunks is not None for b in cpu)  # (cut on the way to the device)
+    got = []
+    for b in io.DevicePrefetcher(cpu, dev):
+        assert b.chunks is not None and b.chunks.ws is not None and b.chunks.ws.device.type == "cuda"
+        got.append(ops.forward_backward(b, theta))
+    assert len(got) == len(want)
+    for a, w in zip(got, want):
+        assert torch.equal(a.logz64, w.logz64) and torch.equal(a.posterior, w.posterior)
