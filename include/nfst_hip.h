@@ -227,6 +227,10 @@ int64_t nfst_chunks_ws_bytes(const nfst_chunks *c);
 
 const char *nfst_strerror(int code);
 int nfst_abi_version(void);
+/* sizeof the named struct of this header ("nfst_batch", "nfst_scores", "nfst_chunks", "nfst_chunk_opts", "nfst_pack_opts",
+ * "nfst_step_extras", "nfst_arcs_device") as the library was compiled, -1 for another name: a binding checks its own
+ * declarations against it (the entry points copy whole structs) */
+int nfst_sizeof(const char *struct_name);
 /* 1 when a HIP device is usable, 0 otherwise (never an error) */
 int nfst_device_available(void);
 

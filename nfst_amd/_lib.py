@@ -102,6 +102,7 @@ def _load():
     sig = {
         "nfst_strerror": (C.c_char_p, [C.c_int]),
         "nfst_abi_version": (C.c_int, []),
+        "nfst_sizeof": (C.c_int, [C.c_char_p]),
         "nfst_device_available": (C.c_int, []),
         "nfst_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
         "nfst_pack_dense": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, C.POINTER(PackOpts), C.POINTER(vp), C.POINTER(i32)]),
@@ -162,6 +163,12 @@ ABI_VERSION = header_abi_version()
 if lib.nfst_abi_version() != ABI_VERSION:
     raise ImportError(f"libnfst_hip.so has ABI {lib.nfst_abi_version()}, include/nfst_hip.h says {ABI_VERSION}; "
                       "rebuild with `python -m nfst_amd.build --force`")
+
+
+for _name, _cls in (("nfst_batch", Batch), ("nfst_scores", Scores), ("nfst_chunks", Chunks), ("nfst_chunk_opts", ChunkOpts),
+                    ("nfst_pack_opts", PackOpts), ("nfst_step_extras", StepExtras), ("nfst_arcs_device", ArcsDevice)):
+    if lib.nfst_sizeof(_name.encode()) != C.sizeof(_cls):  # (the entry points copy whole structs: a drifted declaration corrupts memory)
+        raise ImportError(f"struct {_name}: the library has {lib.nfst_sizeof(_name.encode())} bytes, nfst_amd/_lib.py declares {C.sizeof(_cls)}")
 
 
 def check(code: int, where: str, lattice: int = -1) -> None:

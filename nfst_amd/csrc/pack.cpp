@@ -14,6 +14,7 @@
 #include <limits>
 #include <new>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "nfst_hip.h"
@@ -751,6 +752,19 @@ int nfst_packed_view(const nfst_packed *p, nfst_batch *view) {
 void nfst_packed_free(nfst_packed *p) { delete p; }
 
 int nfst_abi_version(void) { return NFST_ABI_VERSION; }
+
+int nfst_sizeof(const char *name) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "nfst_batch") return (int)sizeof(nfst_batch);
+  if (n == "nfst_scores") return (int)sizeof(nfst_scores);
+  if (n == "nfst_chunks") return (int)sizeof(nfst_chunks);
+  if (n == "nfst_chunk_opts") return (int)sizeof(nfst_chunk_opts);
+  if (n == "nfst_pack_opts") return (int)sizeof(nfst_pack_opts);
+  if (n == "nfst_step_extras") return (int)sizeof(nfst_step_extras);
+  if (n == "nfst_arcs_device") return (int)sizeof(nfst_arcs_device);
+  return -1;
+}
 
 const char *nfst_strerror(int code) {
   switch (code) {

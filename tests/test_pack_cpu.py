@@ -427,3 +427,21 @@ def test_build_guard_on_register_reports():
     rep = os.path.join(os.path.dirname(build.OUT), "libnfst_hip.resources.json")
     if os.path.exists(rep):
         assert build.check_resources(json.load(open(rep))) == []
+
+
+def test_struct_sizes_of_the_bindings_match_the_library():
+    """the entry points copy whole structs: nfst_amd/_lib.py refuses to import when one of its ctypes declarations has drifted
+    from the header (nfst_sizeof); the stub of INTEGRATION.md declares the same nfst_batch"""
+    import ctypes as C
+    import os
+    import re
+    for name, cls in (("nfst_batch", _lib.Batch), ("nfst_scores", _lib.Scores), ("nfst_chunks", _lib.Chunks), ("nfst_chunk_opts", _lib.ChunkOpts),
+                      ("nfst_pack_opts", _lib.PackOpts), ("nfst_step_extras", _lib.StepExtras), ("nfst_arcs_device", _lib.ArcsDevice)):
+        assert _lib.lib.nfst_sizeof(name.encode()) == C.sizeof(cls), name
+    assert _lib.lib.nfst_sizeof(b"no_such_struct") == -1
+    doc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    stub = doc[doc.index("class Batch(C.Structure)"):doc.index("class Scores(C.Structure)")]
+    n32 = len(re.findall(r'"(n_lattices|vocab|max_rows|max_tiles|weighted|reserved0|only_tag|reserved2)"', stub))
+    n64 = len(re.findall(r'"(total_rows|total_arcs|total_dp_arcs|fwd_words|bwd_words|fwd_slots|bwd_slots)"', stub))
+    nptr = len(re.findall(r'"(meta|row_ptr|arc_src|arc_dst|arc_label|arc_w|fwd_stream|bwd_stream|fwd_perm|bwd_perm|arc_sd|arc_l16|chunks|only)"', stub))
+    assert 4 * n32 + 8 * n64 + 8 * nptr == C.sizeof(_lib.Batch)
