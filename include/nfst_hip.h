@@ -181,7 +181,7 @@ typedef struct nfst_batch {
 #define NFST_CHK_POS_OFF 6    /* first position of this program in pos */
 #define NFST_CHK_T_OFF 7      /* first row of this program's T matrix, in units of 64 doubles */
 /* stream entry: operand ring slot (bits 0..5) | last entry of its state (bit 6) | weight zero (bit 7: the entry
- * of a state without arcs) | canonical arc, relative to the lattice (bits 8..31) */
+ * of a state without arcs, and the entries that pad a chunk to a multiple of eight) | canonical arc, relative to the lattice (bits 8..31) */
 #define NFST_CHK_LAST 0x40u
 #define NFST_CHK_ZERO 0x80u
 
@@ -208,7 +208,7 @@ typedef struct nfst_chunks {
 
 typedef struct nfst_chunk_opts {
   int32_t threads;         /* 0 = by batch size: 1024 when every program gets a CU to itself, else 512 */
-  int32_t lds_bytes;       /* 0 = by batch size: 128 KiB / 64 KiB */
+  int32_t lds_bytes;       /* 0 = by batch size: 152 KiB / 64 KiB */
   int32_t force;           /* 1 = cut every batch that can be cut (testing); 0 = only when the cost model of the
                               two flavours says the chunked one is faster */
   int32_t max_chunks;      /* 0 = no limit beside threads / LDS (testing: small values) */
